@@ -1,0 +1,196 @@
+"""ctypes binding of libcrbeam.so (include/crbeam.h).
+
+The library is built in-tree by ``make -C continuum-robot_amd`` (or ``__graft_entry__.build()``)
+into ``continuum_robot/_lib/libcrbeam.so``.  There is no CPU implementation of the stepper:
+if the library is missing, or a launch is attempted without a HIP device, this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libcrbeam.so")
+
+CRB_OK, CRB_EINVAL, CRB_EHIP, CRB_ENODEV, CRB_EUNSUPPORTED = 0, -1, -2, -3, -4
+CRB_F64, CRB_F32 = 0, 1
+CRB_BC_NONE, CRB_BC_FIXED, CRB_BC_PINNED = 0, 1, 2
+CRB_FORCE_DRAG, CRB_FORCE_GRAVITY, CRB_CORRECTED_AXIAL = 1, 2, 4
+CRB_INPUT_NONE, CRB_INPUT_IMPULSE = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class BeamDesc(C.Structure):
+    _fields_ = [
+        ("n_elem", C.c_int32),
+        ("length", _dp),
+        ("elastic_modulus", _dp),
+        ("moment_inertia", _dp),
+        ("density", _dp),
+        ("cross_area", _dp),
+        ("nonlinear", _u8p),
+        ("node_bc", _u8p),
+        ("wetted_area", _dp),
+        ("drag_coef", _dp),
+        ("fluid_density", C.c_double),
+        ("gravity", C.c_double * 3),
+        ("flags", C.c_uint32),
+    ]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "n_beams", "n_elem", "n_node", "n_free", "node_offset", "n_slots", "beams_per_group", "threads",
+        "pcr_levels", "pcr_levels_full", "reserved")]
+
+
+class InputDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("node", C.c_int32),
+        ("dof", C.c_int32),
+        ("reserved", C.c_int32),
+        ("duration", C.c_double),
+        ("amp", C.c_void_p),
+        ("f_held", C.c_void_p),
+    ]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libcrbeam error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libcrbeam.so; raises if it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first (make -C continuum-robot_amd, or "
+            "__graft_entry__.build()).  The beam stepper has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    L.crb_version.restype = i32
+    L.crb_last_error.restype = C.c_char_p
+    L.crb_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(BeamDesc)]
+    L.crb_plan_destroy.argtypes = [vp]
+    L.crb_plan_destroy.restype = None
+    L.crb_plan_get_layout.argtypes = [vp, C.POINTER(Layout)]
+    L.crb_plan_get_free_index.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.crb_plan_get_pcr_tables.argtypes = [vp, _dp, _dp, _dp]
+    L.crb_plan_get_slot_tables.argtypes = [vp, _dp, _dp, _dp, C.POINTER(C.c_int16), C.POINTER(C.c_int32)]
+    L.crb_plan_get_mass.argtypes = [vp, _dp]
+    for name in ("crb_pack_state", "crb_unpack_state", "crb_pack_vec", "crb_unpack_vec", "crb_internal_force"):
+        getattr(L, name).argtypes = [vp, vp, vp, vp]
+    L.crb_rhs.argtypes = [vp, vp, vp, vp, vp]
+    L.crb_step_rk4.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), _dp, vp]
+    L.crb_gather_dof.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != CRB_OK:
+        raise NativeError(rc, load().crb_last_error().decode("utf-8", "replace"))
+
+
+_BC_CODES = {"NONE": CRB_BC_NONE, "FIXED": CRB_BC_FIXED, "PINNED": CRB_BC_PINNED}
+
+
+def node_bc_from_column(boundary_condition):
+    """CSV column -> per-node codes: row i applies to node i, the last node stays free
+    (reference: dynamic_beam_model.py:205-218)."""
+    codes = [_BC_CODES[str(b).upper()] for b in boundary_condition]
+    return np.asarray(codes + [CRB_BC_NONE], dtype=np.uint8)
+
+
+class Plan:
+    """Owner of one ``crb_plan`` (one beam topology x n_beams, one dtype, one device)."""
+
+    def __init__(self, columns, n_beams=1, node_bc=None, fluid_density=0.0, enable_fluid=False,
+                 gravity=(0.0, -9.81, 0.0), enable_gravity=False, corrected_axial=False, dtype="f64", device=0):
+        L = load()
+        f8 = lambda v: np.ascontiguousarray(v, dtype=np.float64)  # noqa: E731
+        self._cols = {k: f8(columns[k]) for k in ("length", "elastic_modulus", "moment_inertia", "density",
+                                                  "cross_area")}
+        n = self._cols["length"].shape[0]
+        self._nl = np.ascontiguousarray([1 if str(t).lower() == "nonlinear" else 0 for t in columns["type"]],
+                                        dtype=np.uint8)
+        bad = [str(t) for t in columns["type"] if str(t).lower() not in ("linear", "nonlinear")]
+        if bad:
+            raise ValueError(f"Invalid element types: {set(bad)}")
+        if node_bc is None:
+            node_bc = node_bc_from_column(columns["boundary_condition"])
+        self._bc = np.ascontiguousarray(node_bc, dtype=np.uint8)
+        if self._bc.shape != (n + 1,):
+            raise ValueError("node_bc must have n_elem + 1 entries")
+        has_fluid_cols = "wetted_area" in columns and "drag_coef" in columns and columns["wetted_area"] is not None
+        self._wet = f8(columns["wetted_area"]) if has_fluid_cols else None
+        self._cd = f8(columns["drag_coef"]) if has_fluid_cols else None
+        d = BeamDesc()
+        d.n_elem = n
+        for k, a in self._cols.items():
+            setattr(d, k, a.ctypes.data_as(_dp))
+        d.nonlinear = self._nl.ctypes.data_as(_u8p)
+        d.node_bc = self._bc.ctypes.data_as(_u8p)
+        d.wetted_area = self._wet.ctypes.data_as(_dp) if self._wet is not None else None
+        d.drag_coef = self._cd.ctypes.data_as(_dp) if self._cd is not None else None
+        d.fluid_density = float(fluid_density)
+        g = np.asarray(gravity, dtype=np.float64)
+        d.gravity[0], d.gravity[1], d.gravity[2] = float(g[0]), float(g[1]), float(g[2])
+        d.flags = ((CRB_FORCE_DRAG if enable_fluid else 0) | (CRB_FORCE_GRAVITY if enable_gravity else 0)
+                   | (CRB_CORRECTED_AXIAL if corrected_axial else 0))
+        self.dtype = {"f64": CRB_F64, "f32": CRB_F32, CRB_F64: CRB_F64, CRB_F32: CRB_F32}[dtype]
+        self.device = int(device)
+        h = C.c_void_p()
+        check(L.crb_plan_create(C.byref(h), self.device, self.dtype, int(n_beams), C.byref(d)))
+        self.h = h
+        lay = Layout()
+        check(L.crb_plan_get_layout(self.h, C.byref(lay)))
+        self.layout = lay
+        for name, _ in Layout._fields_:
+            setattr(self, name, getattr(lay, name))
+        fi = np.empty(self.n_free, dtype=np.int32)
+        check(L.crb_plan_get_free_index(self.h, fi.ctypes.data_as(C.POINTER(C.c_int32))))
+        self.free_index = fi
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                load().crb_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- inspection (host)
+    def mass(self):
+        M = np.empty((self.n_free, self.n_free))
+        check(load().crb_plan_get_mass(self.h, M.ctypes.data_as(_dp)))
+        return M
+
+    def pcr_tables(self):
+        S, lf = self.n_slots, self.pcr_levels_full
+        levels = np.zeros((max(lf, 1), S, 10))
+        final = np.zeros((S, 6))
+        norms = np.zeros(max(lf, 1))
+        check(load().crb_plan_get_pcr_tables(self.h, levels.ctypes.data_as(_dp), final.ctypes.data_as(_dp),
+                                             norms.ctypes.data_as(_dp)))
+        return levels[:lf], final, norms[:lf]
+
+    def slot_tables(self):
+        S = self.n_slots
+        drag, hm, mask = np.zeros(S), np.zeros(S), np.zeros((S, 3))
+        grav = np.zeros((S, 12), dtype=np.int16)
+        kind = np.zeros(S, dtype=np.int32)
+        check(load().crb_plan_get_slot_tables(self.h, drag.ctypes.data_as(_dp), hm.ctypes.data_as(_dp),
+                                              mask.ctypes.data_as(_dp), grav.ctypes.data_as(C.POINTER(C.c_int16)),
+                                              kind.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(drag=drag, half_mass=hm, mask=mask, grav=grav, elem_kind=kind)

@@ -1,0 +1,330 @@
+// crb_math.h -- per-node / per-element arithmetic of the beam hot path.
+//
+// Everything here is a small inline function of VALUES (no memory, no thread ids), so the
+// same source is compiled into the gfx950 kernels (crb_kernels.hip) and, for CPU-only
+// debugging of the kernel arithmetic, into tests/native/crb_emul.cpp (test harness; it is
+// not a product path).  Reference citations are file:line under
+// /root/reference/src/continuum_robot/models/.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CRB_HD __host__ __device__ __forceinline__
+#else
+#define CRB_HD inline
+#endif
+
+namespace crb {
+
+enum : int { KIND_NONE = 0, KIND_LINEAR = 1, KIND_NONLINEAR = 2 };
+
+// Per-element coefficient pack (a1/a3 of SURVEY §8).  One element = the element to the
+// LEFT of a slot's node.
+//   linear    : c = { EA/L, 12EI/L^3, 6EI/L^2, 4EI/L, 2EI/L, 0 }        (segments.py:32-62)
+//   nonlinear : c = { L, EA, EI, 1/L^2, 0.1/L^3, 0 }                     (segments.py:128-130)
+template <typename T>
+struct ElemCoef {
+    T c[6];
+    int32_t kind;
+    int32_t pad;
+};
+
+template <typename T>
+CRB_HD void elem_coef_build(ElemCoef<T>& e, int kind, double L, double E, double I, double A) {
+    const double EA = E * A, EI = E * I;
+    e.kind = kind;
+    e.pad = 0;
+    if (kind == KIND_LINEAR) {
+        e.c[0] = T(EA / L);
+        e.c[1] = T(12 * EI / (L * L * L));
+        e.c[2] = T(6 * EI / (L * L));
+        e.c[3] = T(4 * EI / L);
+        e.c[4] = T(2 * EI / L);
+        e.c[5] = T(0);
+    } else if (kind == KIND_NONLINEAR) {
+        e.c[0] = T(L);
+        e.c[1] = T(EA);
+        e.c[2] = T(EI);
+        e.c[3] = T(1.0 / (L * L));
+        e.c[4] = T(0.1 / (L * L * L));
+        e.c[5] = T(0);
+    } else {
+        for (int i = 0; i < 6; ++i) e.c[i] = T(0);
+    }
+}
+
+// Linear element internal force K_e x_e (segments.py:39-62), split into the halves that go
+// to the left node (fl) and the right node (fr).  ql/qr = [u, w, phi] of the two nodes.
+template <typename T>
+CRB_HD void elem_force_linear(const T* c, const T ql[3], const T qr[3], T fl[3], T fr[3]) {
+    const T du = ql[0] - qr[0];
+    const T dw = ql[1] - qr[1];
+    const T fa = c[0] * du;
+    const T fw = c[1] * dw - c[2] * (ql[2] + qr[2]);
+    const T m0 = -c[2] * dw;
+    fl[0] = fa;
+    fl[1] = fw;
+    fl[2] = m0 + c[3] * ql[2] + c[4] * qr[2];
+    fr[0] = -fa;
+    fr[1] = -fw;
+    fr[2] = m0 + c[4] * ql[2] + c[3] * qr[2];
+}
+
+// Nonlinear (von Karman) element internal force, segments.py:159-472, returned in the
+// reference's order [f1,f3,f4 | f2,f5,f6] = forces on [u1,w1,th1 | u2,w2,th2]
+// (segments.py:146-155).  The 30-term sums are regrouped in a = th1*L, b = th2*L,
+// du = u1-u2, dw = w1-w2; every literal is the reference's.  Where the reference's expanded
+// literals are not exactly 2x / 3x each other (sympy float artefacts such as
+// 7.71428571428601 vs 2*3.857142857143) the remainder is kept as an explicit w1*w2 term, so
+// the regrouped polynomial equals the shipped one identically.  f5 = -f3 term by term in the
+// reference.  corrected == false keeps the shipped f1 (it lacks the
+// -EA/L*u2 coupling); corrected == true uses f1 = -f2.
+template <typename T>
+CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
+    const T L = c[0], A = c[1], D = c[2], iL2 = c[3], tenth_iL3 = c[4];
+    const T u1 = ql[0], w1 = ql[1], u2 = qr[0], w2 = qr[1];
+    const T a = ql[2] * L, b = qr[2] * L;
+    const T du = u1 - u2, dw = w1 - w2;
+    const T ww = w1 * w2, dw2 = dw * dw;
+    const T a2 = a * a, b2 = b * b, ab = a * b;
+    const T Ldu = L * du;
+
+    // ---- f1, f2 (segments.py:178-208, 227-258)
+    const T T0 = T(0.6) * dw - T(0.05) * (a + b);
+    const T P = a * (T(0.0666666666666665) * a - T(0.0166666666666667) * b - T(0.05) * dw) -
+                b * (T(0.0166666666666667) * a - T(0.0666666666666667) * b + T(0.05) * dw);
+    const T f2 = A * iL2 * (P - Ldu + dw * T0);
+    const T f1 = corrected ? -f2 : A * iL2 * (L * u1 - P - (u2 + dw) * T0);
+
+    // ---- f3 = -f5 (segments.py:279-314, 386-421)
+    const T Qa = T(3.8571428571413) * dw2 + T(2.0 * 3.8571428571413 - 7.7142857142826) * ww;
+    const T Qb = T(3.857142857143) * dw2 + T(2.0 * 3.857142857143 - 7.71428571428601) * ww;
+    const T Cw = dw * (T(10.2857142857147) * dw2 + T(3.0 * 10.2857142857147 - 30.857142857144) * ww);
+    const T P3 = T(0.0357142857143344) * (a2 * a + b2 * b) - T(0.107142857143003) * ab * (a + b) +
+                 T(1.28571428571433) * (a2 + b2) * dw + Ldu * (a + b) - a * Qa - b * Qb - T(12.0) * Ldu * dw + Cw;
+    const T f3 = tenth_iL3 * (A * P3 + D * (T(120.0) * dw - T(60.0) * (a + b)));
+
+    // ---- f4 (segments.py:335-365)
+    const T Q4 = T(0.128571428571433) * dw2 + T(2.0 * 0.128571428571433 - 0.257142857142867) * ww;
+    const T C4 = dw * (T(0.128571428571377) * dw2 + T(3.0 * 0.128571428571377 - 0.38571428571413) * ww);
+    const T P4 = T(0.0285714285714391) * a2 * a - T(0.0107142857142861) * a2 * b + T(0.0107142857142719) * a2 * dw +
+                 T(0.00714285714286444) * a * b2 - T(0.0214285714286007) * ab * dw - T(0.133333333333333) * a * Ldu +
+                 a * Q4 - T(0.00357142857143344) * b2 * b - T(0.0107142857142719) * b2 * dw +
+                 T(0.0333333333333333) * b * Ldu + T(0.1) * Ldu * dw - C4;
+    const T f4 = iL2 * (A * P4 + D * (T(4.0) * a + T(2.0) * b - T(6.0) * dw));
+
+    // ---- f6 (segments.py:442-472)
+    const T Q6 = T(0.128571428571428) * dw2 + T(2.0 * 0.128571428571428 - 0.257142857142856) * ww;
+    const T C6 = dw * (T(0.128571428571433) * dw2 + T(3.0 * 0.128571428571433 - 0.3857142857143) * ww);
+    const T P6 = -T(0.00357142857143344) * a2 * a + T(0.00714285714286356) * a2 * b - T(0.0107142857143003) * a2 * dw -
+                 T(0.0107142857142932) * a * b2 - T(0.021428571428558) * ab * dw + T(0.0333333333333333) * a * Ldu +
+                 T(0.0285714285714271) * b2 * b + T(0.0107142857142932) * b2 * dw - T(0.133333333333333) * b * Ldu +
+                 b * Q6 + T(0.1) * Ldu * dw - C6;
+    const T f6 = iL2 * (A * P6 + D * (T(2.0) * a + T(4.0) * b - T(6.0) * dw));
+
+    fl[0] = f1;
+    fl[1] = f3;
+    fl[2] = f4;
+    fr[0] = f2;
+    fr[1] = -f3;
+    fr[2] = f6;
+}
+
+template <typename T>
+CRB_HD void elem_force(const ElemCoef<T>& e, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
+    if (e.kind == KIND_NONLINEAR) {
+        elem_force_nonlinear<T>(e.c, ql, qr, corrected, fl, fr);
+    } else if (e.kind == KIND_LINEAR) {
+        elem_force_linear<T>(e.c, ql, qr, fl, fr);
+    } else {
+        fl[0] = fl[1] = fl[2] = fr[0] = fr[1] = fr[2] = T(0);
+    }
+}
+
+// Gravity of one segment (gravity_forces.py:117-128): half the segment weight, rotated by the
+// segment's mean rotation into [axial, transverse].  half_mass = 0.5*rho*A*L.
+CRB_HD void crb_sincos(double x, double* s, double* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ::sincos(x, s, c);
+#else
+    *s = sin(x);
+    *c = cos(x);
+#endif
+}
+CRB_HD void crb_sincos(float x, float* s, float* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ::sincosf(x, s, c);
+#else
+    *s = sinf(x);
+    *c = cosf(x);
+#endif
+}
+
+template <typename T>
+CRB_HD void gravity_segment(T phi, T gx, T gy, T half_mass, T out[2]) {
+    T s, c;
+    crb_sincos(phi, &s, &c);
+    out[0] = (c * gx + s * gy) * half_mass;
+    out[1] = (c * gy - s * gx) * half_mass;
+}
+
+// Fluid drag on a transverse DOF (fluid_forces.py:138): -c * v * |v|
+template <typename T>
+CRB_HD T drag_force(T coef, T v) {
+    return -coef * v * (v < T(0) ? -v : v);
+}
+
+// ------------------------------------------------------------------ mass blocks / PCR
+// Node-block form of the consistent mass matrix (segments.py:64-78 assembled as in
+// euler_bernoulli_beam.py:139-161).  The axial DOF (u) decouples from bending (w, phi), so a
+// node row carries one scalar triple (a_ax, b_ax, c_ax) and one 2x2 triple (A, B, C), with
+//   A = coupling to the node on the left, B = diagonal block, C = coupling to the right.
+// 2x2 blocks are stored row-major [ww, wp, pw, pp].
+struct NodeBlocks {
+    double a_ax, b_ax, c_ax;
+    double A[4], B[4], C[4];
+};
+
+// contributions of one element (length L, rhoA = rho*A) to its LEFT node's C/B and its RIGHT
+// node's A/B
+CRB_HD void mass_add_as_right_elem(NodeBlocks& n, double L, double rhoA) {
+    // this node is the element's first node: block [0:3,0:3] on the diagonal, [0:3,3:6] to the right
+    const double m = rhoA * L / 420.0;
+    n.b_ax += 140.0 * m;
+    n.c_ax += 70.0 * m;
+    n.B[0] += 156.0 * m;
+    n.B[1] += -22.0 * L * m;
+    n.B[2] += -22.0 * L * m;
+    n.B[3] += 4.0 * L * L * m;
+    n.C[0] += 54.0 * m;
+    n.C[1] += 13.0 * L * m;
+    n.C[2] += -13.0 * L * m;
+    n.C[3] += -3.0 * L * L * m;
+}
+CRB_HD void mass_add_as_left_elem(NodeBlocks& n, double L, double rhoA, bool has_left_node) {
+    // this node is the element's second node: block [3:6,3:6] on the diagonal, [3:6,0:3] to the left
+    const double m = rhoA * L / 420.0;
+    n.b_ax += 140.0 * m;
+    n.B[0] += 156.0 * m;
+    n.B[1] += 22.0 * L * m;
+    n.B[2] += 22.0 * L * m;
+    n.B[3] += 4.0 * L * L * m;
+    if (has_left_node) {
+        n.a_ax += 70.0 * m;
+        n.A[0] += 54.0 * m;
+        n.A[1] += -13.0 * L * m;
+        n.A[2] += 13.0 * L * m;
+        n.A[3] += -3.0 * L * L * m;
+    }
+}
+
+// Boundary conditions (euler_bernoulli_beam.py:240-265) in place of physically removing
+// rows/columns: a constrained DOF keeps its slot, its row/column become the identity.
+// free_* are this node's masks, l_* / r_* the neighbours' (a missing neighbour = not free).
+CRB_HD void mass_apply_masks(NodeBlocks& n, bool fu, bool fw, bool fp, bool lu, bool lw, bool lp, bool ru, bool rw,
+                             bool rp) {
+    if (!fu) { n.a_ax = 0; n.c_ax = 0; n.b_ax = 1; }
+    if (!lu) n.a_ax = 0;
+    if (!ru) n.c_ax = 0;
+    const bool fr[2] = {fw, fp}, lf[2] = {lw, lp}, rf[2] = {rw, rp};
+    for (int r = 0; r < 2; ++r)
+        for (int cc = 0; cc < 2; ++cc) {
+            if (!fr[r] || !lf[cc]) n.A[2 * r + cc] = 0;
+            if (!fr[r] || !rf[cc]) n.C[2 * r + cc] = 0;
+            if (!fr[r] || !fr[cc]) n.B[2 * r + cc] = (r == cc && !fr[r]) ? 1.0 : 0.0;
+        }
+}
+
+CRB_HD void inv2(const double M[4], double R[4]) {
+    const double det = M[0] * M[3] - M[1] * M[2];
+    const double id = 1.0 / det;
+    R[0] = M[3] * id;
+    R[1] = -M[1] * id;
+    R[2] = -M[2] * id;
+    R[3] = M[0] * id;
+}
+CRB_HD void mul2(const double X[4], const double Y[4], double R[4]) {
+    R[0] = X[0] * Y[0] + X[1] * Y[2];
+    R[1] = X[0] * Y[1] + X[1] * Y[3];
+    R[2] = X[2] * Y[0] + X[3] * Y[2];
+    R[3] = X[2] * Y[1] + X[3] * Y[3];
+}
+
+// One level of parallel cyclic reduction on the (constant) mass matrix, factor phase.
+// me = this row, lo = row i-s, hi = row i+s (has_lo / has_hi false outside the beam).
+// Outputs the level's elimination multipliers
+//     al = -A_i * inv(B_lo),  ga = -C_i * inv(B_hi)     (scalar for axial, 2x2 for bending)
+// and the row after the level.  The solve phase only ever needs al/ga:
+//     r_i <- r_i + al * r_{i-s} + ga * r_{i+s}.
+struct PcrLevel {
+    double al_ax, ga_ax;
+    double al[4], ga[4];
+};
+CRB_HD void pcr_factor_level(const NodeBlocks& me, const NodeBlocks& lo, bool has_lo, const NodeBlocks& hi, bool has_hi,
+                             PcrLevel& lv, NodeBlocks& out) {
+    out = me;
+    lv.al_ax = lv.ga_ax = 0.0;
+    for (int k = 0; k < 4; ++k) lv.al[k] = lv.ga[k] = 0.0;
+    out.a_ax = out.c_ax = 0.0;
+    for (int k = 0; k < 4; ++k) out.A[k] = out.C[k] = 0.0;
+    if (has_lo) {
+        lv.al_ax = -me.a_ax / lo.b_ax;
+        out.b_ax += lv.al_ax * lo.c_ax;
+        out.a_ax = lv.al_ax * lo.a_ax;
+        double Bi[4], t[4];
+        inv2(lo.B, Bi);
+        mul2(me.A, Bi, t);
+        for (int k = 0; k < 4; ++k) lv.al[k] = -t[k];
+        mul2(lv.al, lo.C, t);
+        for (int k = 0; k < 4; ++k) out.B[k] += t[k];
+        mul2(lv.al, lo.A, out.A);
+    }
+    if (has_hi) {
+        lv.ga_ax = -me.c_ax / hi.b_ax;
+        out.b_ax += lv.ga_ax * hi.a_ax;
+        out.c_ax = lv.ga_ax * hi.c_ax;
+        double Bi[4], t[4];
+        inv2(hi.B, Bi);
+        mul2(me.C, Bi, t);
+        for (int k = 0; k < 4; ++k) lv.ga[k] = -t[k];
+        mul2(lv.ga, hi.A, t);
+        for (int k = 0; k < 4; ++k) out.B[k] += t[k];
+        mul2(lv.ga, hi.C, out.C);
+    }
+}
+
+// Size of a level's multipliers relative to 1, with the rotation DOF scaled by a
+// characteristic length Lc so that force/moment units compare (used to decide how many
+// levels the solve needs: below ~2^-60 a level no longer changes an fp64 result).
+CRB_HD double pcr_level_norm(const PcrLevel& lv, double Lc) {
+    double m = fabs(lv.al_ax);
+    const double v[9] = {fabs(lv.ga_ax),       fabs(lv.al[0]),      fabs(lv.al[1]) * Lc, fabs(lv.al[2]) / Lc, fabs(lv.al[3]),
+                         fabs(lv.ga[0]),       fabs(lv.ga[1]) * Lc, fabs(lv.ga[2]) / Lc, fabs(lv.ga[3])};
+    for (int k = 0; k < 9; ++k) m = v[k] > m ? v[k] : m;
+    return m;
+}
+
+// Solve-phase tables as the kernels read them (T = plan dtype).
+//   level record : [al_ax, ga_ax, al[4], ga[4]]  -> 10 values per slot per level
+//   final record : [1/b_ax, inv(B)[4]]           -> 5 values per slot (padded to 6)
+constexpr int PCR_LEVEL_VALS = 10;
+constexpr int PCR_FINAL_VALS = 6;
+
+template <typename T>
+CRB_HD void pcr_apply_level(const T* cf, const T rlo[3], const T rhi[3], T r[3]) {
+    const T r0 = r[0] + cf[0] * rlo[0] + cf[1] * rhi[0];
+    const T r1 = r[1] + cf[2] * rlo[1] + cf[3] * rlo[2] + cf[6] * rhi[1] + cf[7] * rhi[2];
+    const T r2 = r[2] + cf[4] * rlo[1] + cf[5] * rlo[2] + cf[8] * rhi[1] + cf[9] * rhi[2];
+    r[0] = r0;
+    r[1] = r1;
+    r[2] = r2;
+}
+template <typename T>
+CRB_HD void pcr_apply_final(const T* cf, const T r[3], T x[3]) {
+    x[0] = cf[0] * r[0];
+    x[1] = cf[1] * r[1] + cf[2] * r[2];
+    x[2] = cf[3] * r[1] + cf[4] * r[2];
+}
+
+}  // namespace crb

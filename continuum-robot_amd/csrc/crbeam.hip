@@ -1,0 +1,557 @@
+// crbeam.hip -- C ABI of libcrbeam.so (include/crbeam.h): plan construction on the host,
+// kernel launches on gfx950.  Build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/crbeam.h"
+#include "crb_kernels.h"
+
+using namespace crb;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) return fail(CRB_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+struct crb_plan {
+    int device = -1, dtype = CRB_F64, B = 0;
+    int n_elem = 0, n_node = 0, n_free = 0, off = 0, S = 0, G = 1, NT = 64;
+    int levels = 0, levels_full = 0;
+    uint32_t flags = 0;
+    double gx = 0, gy = 0;
+    std::vector<int32_t> free_index;  // reduced -> full
+    std::vector<int32_t> full2red;    // full -> reduced or -1
+    std::vector<double> h_levels, h_final, h_norms, h_mass;
+    std::vector<crb::SlotConst<double>> h_slots;
+    std::vector<int> h_kinds;
+    // device
+    void* d_slot = nullptr;
+    void* d_levels = nullptr;
+    void* d_final = nullptr;
+    int32_t* d_free_index = nullptr;
+};
+
+extern "C" int crb_version(void) { return CRB_VERSION; }
+extern "C" const char* crb_last_error(void) { return g_err.c_str(); }
+
+namespace {
+
+struct HostTables {
+    std::vector<SlotConst<double>> slot;
+};
+
+template <typename T>
+SlotConst<T> convert_slot(const SlotConst<double>& s, int kind, double L, double E, double I, double A) {
+    SlotConst<T> o;
+    std::memset(&o, 0, sizeof(o));
+    elem_coef_build<T>(o.elem, kind, L, E, I, A);
+    o.drag = T(s.drag);
+    o.half_mass = T(s.half_mass);
+    for (int c = 0; c < 3; ++c) o.mask[c] = T(s.mask[c]);
+    o.pad0 = T(0);
+    o.grav = s.grav;
+    return o;
+}
+
+template <typename T>
+int upload_tables(crb_plan* p, const std::vector<SlotConst<double>>& slots, const std::vector<int>& kinds,
+                  const crb_beam_desc* d) {
+    const int S = p->S;
+    std::vector<SlotConst<T>> hs(S);
+    for (int j = 0; j < S; ++j) {
+        const int e = j + p->off - 1;
+        if (e >= 0)
+            hs[j] = convert_slot<T>(slots[j], kinds[j], d->length[e], d->elastic_modulus[e], d->moment_inertia[e],
+                                    d->cross_area[e]);
+        else
+            hs[j] = convert_slot<T>(slots[j], KIND_NONE, 1, 1, 1, 1);
+    }
+    std::vector<T> lv(size_t(p->levels > 0 ? p->levels : 1) * S * PCR_LEVEL_VALS, T(0));
+    for (size_t i = 0; i < size_t(p->levels) * S * PCR_LEVEL_VALS; ++i) lv[i] = T(p->h_levels[i]);
+    std::vector<T> fin(size_t(S) * PCR_FINAL_VALS);
+    for (size_t i = 0; i < fin.size(); ++i) fin[i] = T(p->h_final[i]);
+    HIP_TRY(hipMalloc(&p->d_slot, hs.size() * sizeof(SlotConst<T>)));
+    HIP_TRY(hipMalloc(&p->d_levels, lv.size() * sizeof(T)));
+    HIP_TRY(hipMalloc(&p->d_final, fin.size() * sizeof(T)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), p->free_index.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_slot, hs.data(), hs.size() * sizeof(SlotConst<T>), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_levels, lv.data(), lv.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_final, fin.data(), fin.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_free_index, p->free_index.data(), p->free_index.size() * sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    return CRB_OK;
+}
+
+}  // namespace
+
+extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* d) {
+    if (!out || !d) return fail(CRB_EINVAL, "crb_plan_create: null argument");
+    *out = nullptr;
+    if (dtype != CRB_F64 && dtype != CRB_F32) return fail(CRB_EINVAL, "dtype must be CRB_F64 or CRB_F32");
+    if (n_beams < 1) return fail(CRB_EINVAL, "n_beams must be >= 1");
+    const int ne = d->n_elem;
+    if (ne < 1) return fail(CRB_EINVAL, "n_elem must be >= 1");
+    if (!d->length || !d->elastic_modulus || !d->moment_inertia || !d->density || !d->cross_area || !d->nonlinear ||
+        !d->node_bc)
+        return fail(CRB_EINVAL, "beam description has null columns");
+    for (int e = 0; e < ne; ++e) {
+        // Properties.__post_init__ / EulerBernoulliBeam._validate_parameters (abstractions.py:39-53,
+        // euler_bernoulli_beam.py:100-103)
+        if (!(d->length[e] > 0) || !(d->elastic_modulus[e] > 0) || !(d->moment_inertia[e] > 0) ||
+            !(d->density[e] > 0) || !(d->cross_area[e] > 0))
+            return fail(CRB_EINVAL, "All numeric parameters must be positive");
+        if (d->nonlinear[e] > 1) return fail(CRB_EINVAL, "Invalid element type");
+    }
+    const bool drag = d->flags & CRB_FORCE_DRAG, grav = d->flags & CRB_FORCE_GRAVITY;
+    if (drag) {
+        if (!d->wetted_area || !d->drag_coef) return fail(CRB_EINVAL, "drag enabled but wetted_area/drag_coef missing");
+        if (!(d->fluid_density > 0))
+            return fail(CRB_EINVAL, "fluid_density must be positive when fluid effects are enabled");
+        for (int e = 0; e < ne; ++e) {
+            if (d->drag_coef[e] < 0) return fail(CRB_EINVAL, "Drag coefficients cannot be negative");
+            if (d->wetted_area[e] < 0) return fail(CRB_EINVAL, "Wetted areas cannot be negative");
+        }
+    }
+
+    crb_plan* p = new crb_plan();
+    p->device = device;
+    p->dtype = dtype;
+    p->B = n_beams;
+    p->n_elem = ne;
+    p->n_node = ne + 1;
+    p->flags = d->flags;
+    p->gx = d->gravity[0];
+    p->gy = d->gravity[1];
+
+    // boundary conditions -> free masks (euler_bernoulli_beam.py:240-259)
+    const int nn = p->n_node;
+    std::vector<uint8_t> free_dof(size_t(nn) * 3, 1);
+    for (int i = 0; i < nn; ++i) {
+        const int bc = d->node_bc[i];
+        if (bc == CRB_BC_FIXED) free_dof[3 * i] = free_dof[3 * i + 1] = free_dof[3 * i + 2] = 0;
+        else if (bc == CRB_BC_PINNED) free_dof[3 * i] = free_dof[3 * i + 1] = 0;
+        else if (bc != CRB_BC_NONE) { delete p; return fail(CRB_EINVAL, "Unsupported boundary condition type"); }
+    }
+    p->full2red.assign(size_t(nn) * 3, -1);
+    for (int f = 0; f < 3 * nn; ++f)
+        if (free_dof[f]) { p->full2red[f] = int32_t(p->free_index.size()); p->free_index.push_back(f); }
+    p->n_free = int(p->free_index.size());
+    if (p->n_free == 0) { delete p; return fail(CRB_EINVAL, "Cannot constrain all degrees of freedom"); }
+
+    p->off = (d->node_bc[0] == CRB_BC_FIXED) ? 1 : 0;
+    p->S = nn - p->off;
+    const int S = p->S;
+    if (S > 1024) { delete p; return fail(CRB_EUNSUPPORTED, "more than 1024 thread-carried nodes per beam"); }
+    if (S >= 64) { p->G = 1; p->NT = (S + 63) / 64 * 64; }
+    else { p->G = 64 / S; p->NT = 64; }
+    int lf = 0;
+    while ((1 << lf) < S) ++lf;
+    p->levels_full = lf;
+
+    // ---- per-slot constants
+    std::vector<SlotConst<double>> slots(S);
+    std::vector<int> kinds(S, KIND_NONE);
+    const int n = p->n_free;
+    for (int j = 0; j < S; ++j) {
+        SlotConst<double>& s = slots[j];
+        std::memset(&s, 0, sizeof(s));
+        const int node = j + p->off;
+        const int e = node - 1;
+        if (e >= 0) kinds[j] = d->nonlinear[e] ? KIND_NONLINEAR : KIND_LINEAR;
+        for (int c = 0; c < 3; ++c) s.mask[c] = free_dof[3 * node + c] ? 1.0 : 0.0;
+        if (drag && free_dof[3 * node + 1]) {
+            // fluid_forces.py:59-61, 87-90: the node's own segment row, last row repeated for the tip
+            const int row = node < ne ? node : ne - 1;
+            s.drag = 0.5 * d->fluid_density * d->drag_coef[row] * d->wetted_area[row];
+        }
+        GravTab& gt = s.grav;
+        gt.phiA = gt.phiB = -1;
+        for (int c = 0; c < 3; ++c) { gt.segA[c] = gt.segB[c] = -1; gt.comp[c] = 0; }
+        gt.pad = 0;
+        if (grav) {
+            auto enc = [&](int red) -> int16_t {
+                const int f = p->free_index[red];
+                return int16_t(((f / 3) - p->off) * 4 + (f % 3));
+            };
+            if (j < ne) {  // this thread evaluates segment j (gravity_forces.py:97-128)
+                s.half_mass = 0.5 * (d->density[j] * d->cross_area[j] * d->length[j]);
+                const int sp = 3 * j + 2, ep = 3 * (j + 1) + 2;  // indices into the REDUCED vector
+                if (sp < n) gt.phiA = enc(sp);
+                if (ep < n) gt.phiB = enc(ep);
+            }
+            for (int c = 0; c < 3; ++c) {  // which segments add to this DOF (gravity_forces.py:130-146)
+                const int r = p->full2red[3 * node + c];
+                if (r < 0 || r % 3 == 2) continue;
+                gt.comp[c] = int8_t(r % 3);
+                if (r / 3 < ne) gt.segA[c] = int16_t(r / 3);
+                if (r / 3 - 1 >= 0) gt.segB[c] = int16_t(r / 3 - 1);
+            }
+        }
+    }
+
+    p->h_slots = slots;
+    p->h_kinds = kinds;
+
+    // ---- mass matrix in node-block form + cyclic-reduction factorisation (all fp64)
+    std::vector<NodeBlocks> cur(S), nxt(S);
+    auto fm = [&](int node, int c) { return node >= 0 && node < nn && free_dof[3 * node + c] != 0; };
+    for (int j = 0; j < S; ++j) {
+        NodeBlocks nb;
+        std::memset(&nb, 0, sizeof(nb));
+        const int node = j + p->off;
+        const int el = node - 1, er = node;
+        if (el >= 0) mass_add_as_left_elem(nb, d->length[el], d->density[el] * d->cross_area[el], j >= 1);
+        if (er < ne) mass_add_as_right_elem(nb, d->length[er], d->density[er] * d->cross_area[er]);
+        const bool hl = j >= 1, hr = j + 1 < S;
+        mass_apply_masks(nb, fm(node, 0), fm(node, 1), fm(node, 2), hl && fm(node - 1, 0), hl && fm(node - 1, 1),
+                         hl && fm(node - 1, 2), hr && fm(node + 1, 0), hr && fm(node + 1, 1), hr && fm(node + 1, 2));
+        cur[j] = nb;
+    }
+    {   // dense reduced mass for inspection (get_mass_matrix)
+        p->h_mass.assign(size_t(n) * n, 0.0);
+        auto put = [&](int fr, int fc, double v) {
+            const int r = p->full2red[fr], c = p->full2red[fc];
+            if (r >= 0 && c >= 0) p->h_mass[size_t(r) * n + c] += v;
+        };
+        for (int j = 0; j < S; ++j) {
+            const int f0 = 3 * (j + p->off);
+            const NodeBlocks& b = cur[j];
+            put(f0, f0, b.b_ax);
+            for (int r = 0; r < 2; ++r)
+                for (int c = 0; c < 2; ++c) put(f0 + 1 + r, f0 + 1 + c, b.B[2 * r + c]);
+            if (j + 1 < S) {
+                put(f0, f0 + 3, b.c_ax);
+                put(f0 + 3, f0, b.c_ax);
+                for (int r = 0; r < 2; ++r)
+                    for (int c = 0; c < 2; ++c) {
+                        put(f0 + 1 + r, f0 + 4 + c, b.C[2 * r + c]);
+                        put(f0 + 4 + c, f0 + 1 + r, b.C[2 * r + c]);
+                    }
+            }
+        }
+    }
+    std::vector<std::vector<NodeBlocks>> states;
+    states.push_back(cur);
+    p->h_levels.assign(size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS, 0.0);
+    p->h_norms.assign(size_t(lf > 0 ? lf : 1), 0.0);
+    for (int l = 0; l < lf; ++l) {
+        const int s = 1 << l;
+        double nm = 0.0;
+        for (int j = 0; j < S; ++j) {
+            PcrLevel lv;
+            const bool hl = j - s >= 0, hh = j + s < S;
+            pcr_factor_level(cur[j], cur[hl ? j - s : j], hl, cur[hh ? j + s : j], hh, lv, nxt[j]);
+            double* o = &p->h_levels[(size_t(l) * S + j) * PCR_LEVEL_VALS];
+            o[0] = lv.al_ax;
+            o[1] = lv.ga_ax;
+            for (int k = 0; k < 4; ++k) { o[2 + k] = lv.al[k]; o[6 + k] = lv.ga[k]; }
+            const int node = j + p->off;
+            const int el = node - 1 >= 0 ? node - 1 : 0;
+            const double nj = pcr_level_norm(lv, d->length[el < ne ? el : ne - 1]);
+            nm = nj > nm ? nj : nm;
+        }
+        p->h_norms[l] = nm;
+        cur.swap(nxt);
+        states.push_back(cur);
+    }
+    const double tol = (dtype == CRB_F64) ? std::ldexp(1.0, -60) : std::ldexp(1.0, -30);
+    int used = lf;
+    while (used > 0 && p->h_norms[used - 1] < tol) --used;
+    p->levels = used;
+    p->h_final.assign(size_t(S) * PCR_FINAL_VALS, 0.0);
+    for (int j = 0; j < S; ++j) {
+        const NodeBlocks& b = states[used][j];
+        double Bi[4];
+        inv2(b.B, Bi);
+        double* o = &p->h_final[size_t(j) * PCR_FINAL_VALS];
+        o[0] = 1.0 / b.b_ax;
+        for (int k = 0; k < 4; ++k) o[1 + k] = Bi[k];
+        o[5] = 0.0;
+    }
+
+    if (device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) {
+            delete p;
+            return fail(CRB_ENODEV, "crb_plan_create: HIP device not available (no fallback path exists)");
+        }
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { delete p; return fail(CRB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+        const int rc = (dtype == CRB_F64) ? upload_tables<double>(p, slots, kinds, d) : upload_tables<float>(p, slots, kinds, d);
+        if (rc != CRB_OK) { crb_plan_destroy(p); return rc; }
+    }
+    *out = p;
+    return CRB_OK;
+}
+
+extern "C" void crb_plan_destroy(crb_plan* p) {
+    if (!p) return;
+    if (p->device >= 0) {
+        (void)hipFree(p->d_slot);
+        (void)hipFree(p->d_levels);
+        (void)hipFree(p->d_final);
+        (void)hipFree(p->d_free_index);
+    }
+    delete p;
+}
+
+extern "C" int crb_plan_get_layout(const crb_plan* p, crb_layout* o) {
+    if (!p || !o) return fail(CRB_EINVAL, "null argument");
+    o->dtype = p->dtype;
+    o->n_beams = p->B;
+    o->n_elem = p->n_elem;
+    o->n_node = p->n_node;
+    o->n_free = p->n_free;
+    o->node_offset = p->off;
+    o->n_slots = p->S;
+    o->beams_per_group = p->G;
+    o->threads = p->NT;
+    o->pcr_levels = p->levels;
+    o->pcr_levels_full = p->levels_full;
+    o->reserved = 0;
+    return CRB_OK;
+}
+
+extern "C" int crb_plan_get_free_index(const crb_plan* p, int32_t* out) {
+    if (!p || !out) return fail(CRB_EINVAL, "null argument");
+    std::memcpy(out, p->free_index.data(), p->free_index.size() * sizeof(int32_t));
+    return CRB_OK;
+}
+
+extern "C" int crb_plan_get_pcr_tables(const crb_plan* p, double* levels, double* final_, double* norms) {
+    if (!p) return fail(CRB_EINVAL, "null argument");
+    const size_t S = size_t(p->S);
+    if (levels) std::memcpy(levels, p->h_levels.data(), size_t(p->levels_full) * S * PCR_LEVEL_VALS * sizeof(double));
+    if (final_) std::memcpy(final_, p->h_final.data(), S * PCR_FINAL_VALS * sizeof(double));
+    if (norms) std::memcpy(norms, p->h_norms.data(), size_t(p->levels_full) * sizeof(double));
+    return CRB_OK;
+}
+
+extern "C" int crb_plan_get_slot_tables(const crb_plan* p, double* drag, double* half_mass, double* mask, int16_t* grav,
+                                        int32_t* elem_kind) {
+    if (!p) return fail(CRB_EINVAL, "null argument");
+    for (int j = 0; j < p->S; ++j) {
+        const SlotConst<double>& s = p->h_slots[j];
+        if (drag) drag[j] = s.drag;
+        if (half_mass) half_mass[j] = s.half_mass;
+        if (mask) for (int c = 0; c < 3; ++c) mask[3 * j + c] = s.mask[c];
+        if (grav) {
+            int16_t* g = grav + 12 * j;
+            g[0] = s.grav.phiA;
+            g[1] = s.grav.phiB;
+            for (int c = 0; c < 3; ++c) { g[2 + c] = s.grav.segA[c]; g[5 + c] = s.grav.segB[c]; g[8 + c] = s.grav.comp[c]; }
+            g[11] = 0;
+        }
+        if (elem_kind) elem_kind[j] = p->h_kinds[j];
+    }
+    return CRB_OK;
+}
+
+extern "C" int crb_plan_get_mass(const crb_plan* p, double* M) {
+    if (!p || !M) return fail(CRB_EINVAL, "null argument");
+    std::memcpy(M, p->h_mass.data(), p->h_mass.size() * sizeof(double));
+    return CRB_OK;
+}
+
+// ------------------------------------------------------------------ launches
+namespace {
+
+int need_device(const crb_plan* p, const char* who) {
+    if (!p) return fail(CRB_EINVAL, std::string(who) + ": null plan");
+    if (p->device < 0)
+        return fail(CRB_ENODEV, std::string(who) + ": host-only plan; the stepper has no CPU path, a HIP device is required");
+    hipError_t e = hipSetDevice(p->device);
+    if (e != hipSuccess) return fail(CRB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return CRB_OK;
+}
+
+template <typename T>
+KParams<T> base_params(const crb_plan* p) {
+    KParams<T> k;
+    std::memset(&k, 0, sizeof(k));
+    k.slot = static_cast<const SlotConst<T>*>(p->d_slot);
+    k.pcr_levels = static_cast<const T*>(p->d_levels);
+    k.pcr_final = static_cast<const T*>(p->d_final);
+    k.B = p->B;
+    k.S = p->S;
+    k.G = p->G;
+    k.n_node = p->n_node;
+    k.off = p->off;
+    k.levels = p->levels;
+    k.flags = p->flags;
+    k.imp_slot = -1;
+    k.imp_dof = 0;
+    k.duration = 0.0;
+    k.gx = T(p->gx);
+    k.gy = T(p->gy);
+    return k;
+}
+
+template <typename T, int MODE>
+int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);
+    const size_t smem = lds_bytes<T>(p->NT);
+    if (p->NT <= 256)
+        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, 256>), grid, block, smem, st, k);
+    else
+        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, 1024>), grid, block, smem, st, k);
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}
+
+template <typename T>
+int pack_impl(const crb_plan* p, bool pack, int rows, const void* red_in, void* dev, void* red_out, hipStream_t st) {
+    const size_t total = size_t(p->B) * rows * p->n_free;
+    const int bs = 256;
+    const unsigned grid = unsigned((total + bs - 1) / bs);
+    if (pack) {
+        HIP_TRY(hipMemsetAsync(dev, 0, size_t(p->B) * rows * p->n_node * 4 * sizeof(T), st));
+        hipLaunchKernelGGL((crb_pack_kernel<T, true>), dim3(grid), dim3(bs), 0, st, p->d_free_index, p->n_free, p->n_node,
+                           rows, p->B, static_cast<const T*>(red_in), static_cast<T*>(dev), static_cast<T*>(nullptr));
+    } else {
+        hipLaunchKernelGGL((crb_pack_kernel<T, false>), dim3(grid), dim3(bs), 0, st, p->d_free_index, p->n_free, p->n_node,
+                           rows, p->B, static_cast<const T*>(nullptr), static_cast<T*>(dev), static_cast<T*>(red_out));
+    }
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}
+
+int pack_dispatch(const crb_plan* p, bool pack, int rows, const void* red_in, void* dev, void* red_out, void* stream,
+                  const char* who) {
+    if (int rc = need_device(p, who)) return rc;
+    if (!dev || (pack && !red_in) || (!pack && !red_out)) return fail(CRB_EINVAL, std::string(who) + ": null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return p->dtype == CRB_F64 ? pack_impl<double>(p, pack, rows, red_in, dev, red_out, st)
+                               : pack_impl<float>(p, pack, rows, red_in, dev, red_out, st);
+}
+
+}  // namespace
+
+extern "C" int crb_pack_state(const crb_plan* p, const void* x_red, void* x, void* stream) {
+    return pack_dispatch(p, true, 2, x_red, x, nullptr, stream, "crb_pack_state");
+}
+extern "C" int crb_unpack_state(const crb_plan* p, const void* x, void* x_red, void* stream) {
+    return pack_dispatch(p, false, 2, nullptr, const_cast<void*>(x), x_red, stream, "crb_unpack_state");
+}
+extern "C" int crb_pack_vec(const crb_plan* p, const void* v_red, void* v, void* stream) {
+    return pack_dispatch(p, true, 1, v_red, v, nullptr, stream, "crb_pack_vec");
+}
+extern "C" int crb_unpack_vec(const crb_plan* p, const void* v, void* v_red, void* stream) {
+    return pack_dispatch(p, false, 1, nullptr, const_cast<void*>(v), v_red, stream, "crb_unpack_vec");
+}
+
+extern "C" int crb_internal_force(const crb_plan* p, const void* x, void* kout, void* stream) {
+    if (int rc = need_device(p, "crb_internal_force")) return rc;
+    if (!x || !kout) return fail(CRB_EINVAL, "crb_internal_force: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->dtype == CRB_F64) {
+        KParams<double> k = base_params<double>(p);
+        k.x = static_cast<double*>(const_cast<void*>(x));
+        k.out = static_cast<double*>(kout);
+        return launch_beam<double, MODE_KQ>(p, k, st);
+    }
+    KParams<float> k = base_params<float>(p);
+    k.x = static_cast<float*>(const_cast<void*>(x));
+    k.out = static_cast<float*>(kout);
+    return launch_beam<float, MODE_KQ>(p, k, st);
+}
+
+extern "C" int crb_rhs(const crb_plan* p, const void* x, const void* u, void* xdot, void* stream) {
+    if (int rc = need_device(p, "crb_rhs")) return rc;
+    if (!x || !xdot) return fail(CRB_EINVAL, "crb_rhs: null pointer");
+    if (x == xdot) return fail(CRB_EINVAL, "crb_rhs: xdot must not alias x");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->dtype == CRB_F64) {
+        KParams<double> k = base_params<double>(p);
+        k.x = static_cast<double*>(const_cast<void*>(x));
+        k.u_held = static_cast<const double*>(u);
+        k.out = static_cast<double*>(xdot);
+        return launch_beam<double, MODE_RHS>(p, k, st);
+    }
+    KParams<float> k = base_params<float>(p);
+    k.x = static_cast<float*>(const_cast<void*>(x));
+    k.u_held = static_cast<const float*>(u);
+    k.out = static_cast<float*>(xdot);
+    return launch_beam<float, MODE_RHS>(p, k, st);
+}
+
+extern "C" int crb_step_rk4(const crb_plan* p, void* x, double t0, double dt, int n_steps, const crb_input_desc* in,
+                            double* t_end, void* stream) {
+    if (int rc = need_device(p, "crb_step_rk4")) return rc;
+    if (!x) return fail(CRB_EINVAL, "crb_step_rk4: null state");
+    if (n_steps < 0) return fail(CRB_EINVAL, "crb_step_rk4: n_steps must be >= 0");
+    if (!(dt > 0)) return fail(CRB_EINVAL, "crb_step_rk4: dt must be positive");
+    int imp_slot = -1, imp_dof = 0;
+    double duration = 0.0;
+    const void* amp = nullptr;
+    const void* held = nullptr;
+    if (in) {
+        held = in->f_held;
+        if (in->kind == CRB_INPUT_IMPULSE) {
+            if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2)
+                return fail(CRB_EINVAL, "crb_step_rk4: impulse node/dof out of range");
+            if (!in->amp) return fail(CRB_EINVAL, "crb_step_rk4: impulse amplitude array is null");
+            if (p->full2red[3 * in->node + in->dof] < 0)
+                return fail(CRB_EINVAL, "crb_step_rk4: impulse targets a constrained DOF");
+            imp_slot = in->node - p->off;
+            imp_dof = in->dof;
+            duration = in->duration;
+            amp = in->amp;
+        } else if (in->kind != CRB_INPUT_NONE) {
+            return fail(CRB_EINVAL, "crb_step_rk4: unknown input kind");
+        }
+    }
+    // the clock the kernel will hold after n_steps additions (same fp64 additions on the host)
+    if (t_end) {
+        double t = t0;
+        for (int i = 0; i < n_steps; ++i) t = t + dt;
+        *t_end = t;
+    }
+    if (n_steps == 0) return CRB_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->dtype == CRB_F64) {
+        KParams<double> k = base_params<double>(p);
+        k.x = static_cast<double*>(x);
+        k.u_held = static_cast<const double*>(held);
+        k.amp = static_cast<const double*>(amp);
+        k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+        k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+        return launch_beam<double, MODE_STEP>(p, k, st);
+    }
+    KParams<float> k = base_params<float>(p);
+    k.x = static_cast<float*>(x);
+    k.u_held = static_cast<const float*>(held);
+    k.amp = static_cast<const float*>(amp);
+    k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+    k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+    return launch_beam<float, MODE_STEP>(p, k, st);
+}
+
+extern "C" int crb_gather_dof(const crb_plan* p, const void* x, int plane, int node, int dof, void* out, void* stream) {
+    if (int rc = need_device(p, "crb_gather_dof")) return rc;
+    if (!x || !out) return fail(CRB_EINVAL, "crb_gather_dof: null pointer");
+    if (plane < 0 || plane > 1 || node < 0 || node >= p->n_node || dof < 0 || dof > 2)
+        return fail(CRB_EINVAL, "crb_gather_dof: index out of range");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t stride = size_t(2) * p->n_node * 4, off = (size_t(plane) * p->n_node + node) * 4 + dof;
+    const int bs = 256, grid = (p->B + bs - 1) / bs;
+    if (p->dtype == CRB_F64)
+        hipLaunchKernelGGL((crb_gather_kernel<double>), dim3(grid), dim3(bs), 0, st, static_cast<const double*>(x), stride,
+                           off, p->B, static_cast<double*>(out));
+    else
+        hipLaunchKernelGGL((crb_gather_kernel<float>), dim3(grid), dim3(bs), 0, st, static_cast<const float*>(x), stride, off,
+                           p->B, static_cast<float*>(out));
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}

@@ -1,0 +1,158 @@
+/*
+ * crbeam.h -- C ABI of libcrbeam.so, the MI355X (gfx950) beam-dynamics stepper.
+ *
+ * The reference (cram9030/continuum-robot, pure Python) has no FFI/plugin interface: its
+ * boundary for this path is the Python class API of
+ * src/continuum_robot/models/dynamic_beam_model.py (DynamicEulerBernoulliBeam) and the
+ * scipy.solve_ivp call sites that step its RHS.  This header is the native boundary a
+ * maintainer binds with ctypes; every entry point names the reference
+ * interface it stands in for.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Conventions
+ *   - every function returns 0 (CRB_OK) or a negative CRB_E* code; crb_last_error() returns
+ *     a thread-local message for the last failure on the calling thread.
+ *   - "device pointer" = HIP device memory of the plan's device and dtype; the caller owns
+ *     all state/force tensors, the library owns only what hangs off the opaque plan.
+ *   - launches are asynchronous on the passed stream (a hipStream_t passed as void*; NULL =
+ *     the default stream).  A plan is not thread-safe; distinct plans are independent.
+ *   - device state layout  x[B][2][n_node][4] : plane 0 = positions, plane 1 = velocities,
+ *     record = {u, w, phi, 0}.  This is the reference's interleaved full DOF order
+ *     (euler_bernoulli_beam.py:111-133) padded to 32-byte (fp64) / 16-byte (fp32) records;
+ *     constrained DOFs keep their slot and hold 0.  Generalised-force tensors use
+ *     f[B][n_node][4] the same way.  crb_pack_* / crb_unpack_* convert to and from the
+ *     reference's REDUCED ordering (euler_bernoulli_beam.py:258-259, state = [q_red ; v_red],
+ *     dynamic_beam_model.py:135-145).
+ */
+#ifndef CRBEAM_H
+#define CRBEAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRB_VERSION 100
+
+enum { CRB_OK = 0, CRB_EINVAL = -1, CRB_EHIP = -2, CRB_ENODEV = -3, CRB_EUNSUPPORTED = -4 };
+enum { CRB_F64 = 0, CRB_F32 = 1 };
+enum { CRB_BC_NONE = 0, CRB_BC_FIXED = 1, CRB_BC_PINNED = 2 }; /* abstractions.py:16-20 */
+enum {
+    CRB_FORCE_DRAG = 1u,      /* FluidDragForce auto-registration, dynamic_beam_model.py:223-231 */
+    CRB_FORCE_GRAVITY = 2u,   /* GravityForce auto-registration,   dynamic_beam_model.py:234-241 */
+    CRB_CORRECTED_AXIAL = 4u  /* opt-in f1 = -f2 instead of the shipped f1 (segments.py:178-208) */
+};
+enum { CRB_INPUT_NONE = 0, CRB_INPUT_IMPULSE = 1 };
+
+typedef struct crb_plan crb_plan;
+
+/* One beam topology shared by all beams of the ensemble: the CSV schema of
+ * dynamic_beam_model.py:78-90 plus ForceParams (force_params.py:16-22).  Host pointers. */
+typedef struct crb_beam_desc {
+    int32_t n_elem;
+    const double* length;          /* [n_elem] */
+    const double* elastic_modulus; /* [n_elem] */
+    const double* moment_inertia;  /* [n_elem] */
+    const double* density;         /* [n_elem] */
+    const double* cross_area;      /* [n_elem] */
+    const uint8_t* nonlinear;      /* [n_elem] CSV 'type': 0 linear, 1 nonlinear */
+    const uint8_t* node_bc;        /* [n_elem+1] CRB_BC_* per NODE (CSV row i -> node i, last node free) */
+    const double* wetted_area;     /* [n_elem] or NULL when CRB_FORCE_DRAG is off */
+    const double* drag_coef;       /* [n_elem] or NULL */
+    double fluid_density;          /* ForceParams.fluid_density */
+    double gravity[3];             /* ForceParams.gravity_vector (gz unused, gravity_forces.py:18) */
+    uint32_t flags;                /* CRB_FORCE_* | CRB_CORRECTED_AXIAL */
+} crb_beam_desc;
+
+typedef struct crb_layout {
+    int32_t dtype;        /* CRB_F64 / CRB_F32 */
+    int32_t n_beams;
+    int32_t n_elem;
+    int32_t n_node;       /* n_elem + 1 */
+    int32_t n_free;       /* size n of the reference's reduced position vector */
+    int32_t node_offset;  /* 1 when node 0 is FIXED and therefore has no thread slot, else 0 */
+    int32_t n_slots;      /* nodes carried by threads = n_node - node_offset */
+    int32_t beams_per_group; /* beams handled by one workgroup */
+    int32_t threads;      /* workgroup size */
+    int32_t pcr_levels;   /* cyclic-reduction levels the mass solve applies */
+    int32_t pcr_levels_full; /* ceil(log2(n_slots)): levels of the untruncated reduction */
+    int32_t reserved;
+} crb_layout;
+
+/* External generalised force u(t) added to the right-hand side, the `u` of
+ * get_dynamic_system()(t, x, u) (dynamic_beam_model.py:343-362).
+ *   held    : f_held[B][n_node][4] (device, may be NULL) is constant over the call.
+ *   impulse : the examples' forcing (example_utilities.py:144-148, lqr_control.py:33-41):
+ *             amp[b] on DOF (node, dof) while t < duration, else 0; evaluated at every RK4
+ *             stage time. */
+typedef struct crb_input_desc {
+    int32_t kind;        /* CRB_INPUT_NONE / CRB_INPUT_IMPULSE */
+    int32_t node;        /* impulse: node index (0..n_elem) */
+    int32_t dof;         /* impulse: 0 = u, 1 = w, 2 = phi */
+    int32_t reserved;
+    double duration;     /* impulse: seconds */
+    const void* amp;     /* impulse: device [B], plan dtype */
+    const void* f_held;  /* device [B][n_node][4] or NULL */
+} crb_input_desc;
+
+int crb_version(void);
+const char* crb_last_error(void);
+
+/* Builds everything DynamicEulerBernoulliBeam.__init__ precomputes (dynamic_beam_model.py:25-74):
+ * element coefficient packs (segments.py:32-78), the boundary-condition masks
+ * (euler_bernoulli_beam.py:221-298), the mass matrix in node-block form and its cyclic-reduction
+ * factorisation (replaces M_inv = inv(M), dynamic_beam_model.py:60), drag factors
+ * (fluid_forces.py:50-101) and the gravity index table (gravity_forces.py:97-146).
+ * device >= 0: HIP device ordinal, tables are uploaded.  device == -1: host-only plan for
+ * inspection (crb_plan_get_* work, every launch returns CRB_ENODEV). */
+int crb_plan_create(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* desc);
+void crb_plan_destroy(crb_plan* plan);
+int crb_plan_get_layout(const crb_plan* plan, crb_layout* out);
+/* reduced index -> full index 3*node+dof, ascending (euler_bernoulli_beam.py:258-259); [n_free] host */
+int crb_plan_get_free_index(const crb_plan* plan, int32_t* full_index);
+/* Host copies of the solve tables in fp64, for inspection/tests:
+ *   levels [pcr_levels_full][n_slots][10], final_ [n_slots][6] (computed after `pcr_levels`
+ *   levels), norms [pcr_levels_full].  Any pointer may be NULL. */
+int crb_plan_get_pcr_tables(const crb_plan* plan, double* levels, double* final_, double* norms);
+/* Host copies of the per-slot constants the kernels keep in registers, for inspection/tests:
+ *   drag [n_slots], half_mass [n_slots], mask [n_slots][3],
+ *   grav [n_slots][12] = {phiA, phiB, segA[3], segB[3], comp[3], 0} (see crb_kernels.h GravTab),
+ *   elem_kind [n_slots] (0 none, 1 linear, 2 nonlinear; the element LEFT of the slot's node).
+ * Any pointer may be NULL. */
+int crb_plan_get_slot_tables(const crb_plan* plan, double* drag, double* half_mass, double* mask, int16_t* grav,
+                             int32_t* elem_kind);
+/* Dense reduced mass matrix as assembled by the plan, [n_free][n_free] host fp64
+ * (EulerBernoulliBeam.get_mass_matrix, euler_bernoulli_beam.py:358-362). */
+int crb_plan_get_mass(const crb_plan* plan, double* M);
+
+/* reduced [B][2n] <-> device layout [B][2][n_node][4]  (stiffness_with_boundary's
+ * scatter/gather, euler_bernoulli_beam.py:280-289, done once at the API edge) */
+int crb_pack_state(const crb_plan* plan, const void* x_red, void* x, void* stream);
+int crb_unpack_state(const crb_plan* plan, const void* x, void* x_red, void* stream);
+/* reduced [B][n] <-> device layout [B][n_node][4] for force / position-like vectors */
+int crb_pack_vec(const crb_plan* plan, const void* v_red, void* v, void* stream);
+int crb_unpack_vec(const crb_plan* plan, const void* v, void* v_red, void* stream);
+
+/* k(q): EulerBernoulliBeam.get_stiffness_function() (euler_bernoulli_beam.py:163-219, 270-289).
+ * x: device state (only the position plane is read); k: device [B][n_node][4]. */
+int crb_internal_force(const crb_plan* plan, const void* x, void* k, void* stream);
+
+/* xdot = [v ; Minv(-k(q) + f_drag + f_gravity + u)]: get_dynamic_system()(t, x, u)
+ * (dynamic_beam_model.py:256-272, 294-328, 343-362).  u: device [B][n_node][4] or NULL. */
+int crb_rhs(const crb_plan* plan, const void* x, const void* u, void* xdot, void* stream);
+
+/* n_steps classical RK4 steps of size dt, in place, in ONE launch (replaces the
+ * scipy.solve_ivp call sites example_utilities.py:153-159, lqr_control.py:117-125).  The clock
+ * starts at t0 and accumulates by addition (t <- t + dt); stage times t, t+dt/2, t+dt.
+ * *t_end (host, may be NULL) receives the final clock value, to be passed as the next t0. */
+int crb_step_rk4(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const crb_input_desc* input,
+                 double* t_end, void* stream);
+
+/* out[b] = x[b][plane][node][dof]  (e.g. tip displacement = plane 0, node n_elem, dof 1;
+ * lqr_control.py:168) */
+int crb_gather_dof(const crb_plan* plan, const void* x, int plane, int node, int dof, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRBEAM_H */

@@ -1,0 +1,393 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference package is imported read-only from /root/reference/src; nothing is
+written there.  Every fixture is data: beam definitions (the CSV columns), seeded
+input states and the reference's outputs on them.  SURVEY.md §8(c) lists what is
+pinned (G1..G5).  The fixed-step RK4 loop below is OURS (the reference has no
+integrator, every caller hands its RHS to scipy.solve_ivp); it is the loop the
+oracle and the HIP stepper restate:
+
+    k1 = f(t, x, u(t)) ; k2 = f(t+dt/2, x+dt/2*k1, u(t+dt/2))
+    k3 = f(t+dt/2, x+dt/2*k2, u(t+dt/2)) ; k4 = f(t+dt, x+dt*k3, u(t+dt))
+    x <- x + dt/6*(k1 + 2*k2 + 2*k3 + k4) ;  t <- t + dt      (time ACCUMULATES by addition)
+
+The accumulate-by-addition clock is the convention under which SURVEY.md §8(c)'s anchors
+were measured (it decides on which stage the `t < 0.01` impulse of
+examples/example_utilities.py:144-148 switches off); the script prints the anchors.
+"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REF_SRC = "/root/reference/src"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF_SRC)
+
+import pandas as pd  # noqa: E402
+from continuum_robot.models.abstractions import (  # noqa: E402
+    BoundaryConditionType,
+    Properties,
+)
+from continuum_robot.models.dynamic_beam_model import DynamicEulerBernoulliBeam  # noqa: E402
+from continuum_robot.models.euler_bernoulli_beam import EulerBernoulliBeam  # noqa: E402
+from continuum_robot.models.force_params import ForceParams  # noqa: E402
+from continuum_robot.models.segments import LinearSegment, NonlinearSegment  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+COLS = [
+    "length",
+    "elastic_modulus",
+    "moment_inertia",
+    "density",
+    "cross_area",
+    "type",
+    "boundary_condition",
+    "wetted_area",
+    "drag_coef",
+]
+
+
+# --------------------------------------------------------------------------- beams
+def nitinol(n, kind, bcs=None):
+    """Synthetic beam with the Nitinol constants of examples/example_utilities.py:25-34."""
+    r = 0.005
+    L = 0.25
+    kinds = [kind] * n if isinstance(kind, str) else list(kind)
+    bcs = bcs or (["FIXED"] + ["NONE"] * (n - 1))
+    return pd.DataFrame(
+        {
+            "length": [L] * n,
+            "elastic_modulus": [75e9] * n,
+            "moment_inertia": [np.pi * r**4 / 4] * n,
+            "density": [6450.0] * n,
+            "cross_area": [np.pi * r**2] * n,
+            "type": kinds,
+            "boundary_condition": bcs,
+            "wetted_area": [2 * np.pi * r * L] * n,
+            "drag_coef": [0.82] * n,
+        }
+    )
+
+
+def test4(kind, bcs=None):
+    """The 4-segment beam of tests/test_dynamic_beam.py:22-41 (values are data)."""
+    n = 4
+    bcs = bcs or ["FIXED", "NONE", "NONE", "NONE"]
+    return pd.DataFrame(
+        {
+            "length": [0.25] * n,
+            "elastic_modulus": [75e9] * n,
+            "moment_inertia": [4.91e-10] * n,
+            "density": [6450.0] * n,
+            "cross_area": [7.85e-5] * n,
+            "type": [kind] * n,
+            "boundary_condition": bcs,
+            "wetted_area": [0.001] * n,
+            "drag_coef": [0.5] * n,
+        }
+    )
+
+
+def mixed5(bcs=None):
+    """The 5-segment mixed beam of tests/test_advanced_composition.py:15-20."""
+    n = 5
+    bcs = bcs or ["FIXED", "NONE", "NONE", "NONE", "NONE"]
+    return pd.DataFrame(
+        {
+            "length": [0.2] * n,
+            "elastic_modulus": [200e9] * n,
+            "moment_inertia": [1e-8] * n,
+            "density": [8000.0] * n,
+            "cross_area": [1e-4] * n,
+            "type": ["linear", "linear", "nonlinear", "nonlinear", "nonlinear"],
+            "boundary_condition": bcs,
+            "wetted_area": [1e-4] * n,
+            "drag_coef": [1.2] * n,
+        }
+    )
+
+
+def hetero7(bcs=None):
+    """Heterogeneous 7-segment beam (ours): every column varies along the beam."""
+    n = 7
+    rng = np.random.default_rng(77)
+    bcs = bcs or ["FIXED"] + ["NONE"] * (n - 1)
+    return pd.DataFrame(
+        {
+            "length": 0.15 + 0.2 * rng.random(n),
+            "elastic_modulus": 75e9 * (0.8 + 0.4 * rng.random(n)),
+            "moment_inertia": 4.9e-10 * (0.7 + 0.6 * rng.random(n)),
+            "density": 6450.0 * (0.8 + 0.4 * rng.random(n)),
+            "cross_area": 7.85e-5 * (0.8 + 0.4 * rng.random(n)),
+            "type": ["nonlinear", "linear", "linear", "nonlinear", "nonlinear", "linear", "nonlinear"],
+            "boundary_condition": bcs,
+            "wetted_area": 0.001 * (0.5 + rng.random(n)),
+            "drag_coef": 0.3 + rng.random(n),
+        }
+    )
+
+
+def df_arrays(prefix, df):
+    out = {}
+    for c in COLS:
+        v = df[c].to_numpy()
+        out[f"{prefix}/{c}"] = v.astype(str) if c in ("type", "boundary_condition") else v.astype(np.float64)
+    return out
+
+
+def write_csv(df):
+    f = tempfile.NamedTemporaryFile(mode="w", delete=False, suffix=".csv")
+    df[COLS].to_csv(f, index=False)
+    f.close()
+    return f.name
+
+
+# --------------------------------------------------------------------------- G1
+def g1_elements():
+    out = {}
+    r = 0.005
+    mats = np.array(
+        [
+            [1.0, 200e9, 1e-6, 7850.0, 1e-4],
+            [0.25, 75e9, np.pi * r**4 / 4, 6450.0, np.pi * r**2],
+            [0.2, 200e9, 1e-8, 8000.0, 1e-4],
+        ]
+    )
+    rng = np.random.default_rng(101)
+    states = np.vstack([[0.01, 0.001, 0.1, 0.02, 0.002, 0.2], rng.normal(0.0, 1e-2, (16, 6))])
+    K, M, F = [], [], []
+    for L, E, I, rho, A in mats:
+        lin = LinearSegment(Properties(L, E, I, rho, A, 0, "linear"))
+        nl = NonlinearSegment(Properties(L, E, I, rho, A, 0, "nonlinear"))
+        K.append(lin.get_stiffness_func())
+        M.append(lin.get_mass_matrix())
+        assert np.array_equal(M[-1], nl.get_mass_matrix())
+        fn = nl.get_stiffness_func()
+        F.append(np.array([fn(s) for s in states]))
+    out["materials"] = mats  # columns: L, E, I, rho, A
+    out["states"] = states
+    out["K_e"] = np.array(K)
+    out["M_e"] = np.array(M)
+    out["f_nl"] = np.array(F)  # [material, state, 6] in the reference's output order
+    np.savez_compressed(os.path.join(HERE, "g1_elements.npz"), **out)
+    print("G1 anchor f_nl[0,0] =", repr(out["f_nl"][0, 0]))
+
+
+# --------------------------------------------------------------------------- G2
+BC_SETS = {
+    "none": {},
+    "fixed0": {0: "fixed"},
+    "pinned0": {0: "pinned"},
+    "fixed0_pinned2": {0: "fixed", 2: "pinned"},
+    "pinned0_pinnedN": {0: "pinned", -1: "pinned"},
+}
+
+
+def g2_assembly():
+    out = {}
+    beams = {"test4_lin": test4("linear"), "test4_nl": test4("nonlinear"), "mixed5": mixed5(), "hetero7": hetero7()}
+    rng = np.random.default_rng(202)
+    for bname, df in beams.items():
+        out.update(df_arrays(f"{bname}", df))
+        n_nodes = len(df) + 1
+        for sname, bcs in BC_SETS.items():
+            key = f"{bname}/{sname}"
+            beam = EulerBernoulliBeam(df)
+            conds = {
+                (k if k >= 0 else n_nodes + k): BoundaryConditionType(v) for k, v in bcs.items()
+            }
+            node_bc = np.zeros(n_nodes, dtype=np.int32)
+            for k, v in conds.items():
+                node_bc[k] = 1 if v == BoundaryConditionType.FIXED else 2
+            if conds:
+                beam.apply_boundary_conditions(conds)
+            M = beam.get_mass_matrix()
+            n = M.shape[0]
+            out[f"{key}/node_bc"] = node_bc
+            out[f"{key}/M"] = M
+            out[f"{key}/constrained"] = np.array(sorted(beam.get_constrained_dofs()), dtype=np.int32)
+            names = {"u": 0, "w": 1, "phi": 2}
+            out[f"{key}/dof_param"] = np.array([names[beam.dof_to_node_param[i][0]] for i in range(n)], dtype=np.int32)
+            out[f"{key}/dof_node"] = np.array([beam.dof_to_node_param[i][1] for i in range(n)], dtype=np.int32)
+            if not beam.is_hybrid() and bname == "test4_lin":
+                out[f"{key}/K"] = beam.get_stiffness_matrix()
+            q = rng.normal(0.0, 1e-2, (3, n))
+            out[f"{key}/q"] = q
+            out[f"{key}/k_q"] = np.array([beam.get_stiffness_function()(qq) for qq in q])
+    np.savez_compressed(os.path.join(HERE, "g2_assembly.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G3/G4
+FORCE_SETS = {
+    "none": dict(),
+    "drag": dict(fluid_density=1000.0, enable_fluid_effects=True),
+    "grav": dict(enable_gravity_effects=True),
+    "both": dict(fluid_density=1000.0, enable_fluid_effects=True, enable_gravity_effects=True),
+    "grav_xy": dict(gravity_vector=[3.0, -9.81, 0.0], enable_gravity_effects=True),
+    "both_xy": dict(
+        fluid_density=870.0, enable_fluid_effects=True, gravity_vector=[3.0, -9.81, 0.5], enable_gravity_effects=True
+    ),
+}
+
+DYN_BEAMS = {
+    "test4_lin": lambda: test4("linear"),
+    "test4_nl": lambda: test4("nonlinear"),
+    "mixed5": lambda: mixed5(),
+    "hetero7": lambda: hetero7(),
+    "test4_nl_pinned0": lambda: test4("nonlinear", ["PINNED", "NONE", "NONE", "NONE"]),
+    "mixed5_fixed0_pinned2": lambda: mixed5(["FIXED", "NONE", "PINNED", "NONE", "NONE"]),
+    "hetero7_free": lambda: hetero7(["NONE"] * 7),
+    "hetero7_pinned0_fixed3": lambda: hetero7(["PINNED", "NONE", "NONE", "FIXED", "NONE", "NONE", "NONE"]),
+}
+
+
+def fp_arrays(prefix, kw):
+    fp = ForceParams(**kw)
+    return {
+        f"{prefix}/fluid_density": np.float64(fp.fluid_density),
+        f"{prefix}/enable_fluid": np.int32(fp.enable_fluid_effects),
+        f"{prefix}/gravity": fp.get_gravity_vector(),
+        f"{prefix}/enable_gravity": np.int32(fp.enable_gravity_effects),
+    }
+
+
+def g34_forces_rhs():
+    out = {}
+    rng = np.random.default_rng(303)
+    for bname, mk in DYN_BEAMS.items():
+        df = mk()
+        path = write_csv(df)
+        # store the columns as the reference PARSED them (pandas' default read_csv float
+        # parser is not round-trip exact, so these differ from df by a few ulp)
+        out.update(df_arrays(bname, pd.read_csv(path)))
+        try:
+            for fname, kw in FORCE_SETS.items():
+                key = f"{bname}/{fname}"
+                out.update(fp_arrays(key, kw))
+                beam = DynamicEulerBernoulliBeam(path, force_params=ForceParams(**kw))
+                beam.create_system_func()
+                beam.create_input_func()
+                n = beam.beam_model.M.shape[0]
+                X = rng.normal(0.0, 1e-2, (3, 2 * n))
+                X[0, n:] *= 50.0  # larger velocities: drag matters
+                out[f"{key}/x"] = X
+                out[f"{key}/M_inv"] = beam.M_inv.toarray() if fname == "none" else np.zeros(0)
+                out[f"{key}/constrained"] = np.array(sorted(beam.constrained_dofs), dtype=np.int32)
+                forces = beam.force_registry.get_registered_forces()
+                agg = beam.force_registry.create_aggregated_function()
+                out[f"{key}/f_total"] = np.array([agg(x, 0.0) for x in X])
+                for f in forces:
+                    nm = type(f).__name__
+                    out[f"{key}/{nm}"] = np.array([f.compute_forces(x, 0.0) for x in X])
+                    if nm == "FluidDragForce":
+                        fc = f.fluid_coefficients
+                        out[f"{key}/drag_w_vel_indices"] = np.array(fc["w_vel_indices"], dtype=np.int32)
+                        out[f"{key}/drag_w_pos_indices"] = np.array(fc["w_pos_indices"], dtype=np.int32)
+                        out[f"{key}/drag_factors"] = np.array(fc["drag_factors"], dtype=np.float64)
+                dyn = beam.get_dynamic_system()
+                u_tip = np.zeros(n)
+                u_tip[-2] = 0.1
+                U = np.vstack([np.zeros(n), np.ones(n), u_tip, rng.normal(0.0, 1.0, n)])
+                out[f"{key}/u"] = U
+                out[f"{key}/xdot"] = np.array([[dyn(0.0, x, u) for u in U] for x in X])
+        finally:
+            os.unlink(path)
+    np.savez_compressed(os.path.join(HERE, "g34_forces_rhs.npz"), **out)
+
+
+# --------------------------------------------------------------------------- G5
+def rk4(dyn, u_of_t, x0, t0, dt, n_steps, checkpoints=()):
+    x = x0.copy()
+    snaps = {}
+    t = t0
+    for n in range(n_steps):
+        th = t + 0.5 * dt
+        t1 = t + dt
+        k1 = dyn(t, x, u_of_t(t))
+        k2 = dyn(th, x + (0.5 * dt) * k1, u_of_t(th))
+        k3 = dyn(th, x + (0.5 * dt) * k2, u_of_t(th))
+        k4 = dyn(t1, x + dt * k3, u_of_t(t1))
+        x = x + (dt / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        t = t + dt
+        if (n + 1) in checkpoints:
+            snaps[n + 1] = x.copy()
+    return x, snaps
+
+
+def g5_rollouts():
+    out = {}
+    dt = 2e-5
+    jobs = [
+        # name, df, force kw, amp, checkpoints, random x0?
+        ("lin10_grav", nitinol(10, "linear"), dict(enable_gravity_effects=True), 0.1, (1000, 5000), False),
+        ("lin64_grav", nitinol(64, "linear"), dict(enable_gravity_effects=True), 0.1, (200, 1000), False),
+        ("lin64_grav_x0", nitinol(64, "linear"), dict(enable_gravity_effects=True), 0.137, (200, 1000), True),
+        ("nl64_drag", nitinol(64, "nonlinear"), dict(fluid_density=1000.0, enable_fluid_effects=True), 0.1, (200, 1000), False),
+        ("nl256_drag", nitinol(256, "nonlinear"), dict(fluid_density=1000.0, enable_fluid_effects=True), 0.1, (200, 1000), False),
+        ("nl256_drag_a2", nitinol(256, "nonlinear"), dict(fluid_density=1000.0, enable_fluid_effects=True), 0.2, (200,), False),
+        ("mixed5_both", mixed5(), FORCE_SETS["both_xy"], 0.5, (300,), False),
+        ("hetero7_both", hetero7(), FORCE_SETS["both"], 0.3, (300,), False),
+        ("hetero7_p0f3_grav", hetero7(["PINNED", "NONE", "NONE", "FIXED", "NONE", "NONE", "NONE"]), FORCE_SETS["grav_xy"], 0.3, (300,), False),
+    ]
+    for name, df, kw, amp, cps, rand_x0 in jobs:
+        t_start = time.time()
+        out.update(fp_arrays(name, kw))
+        path = write_csv(df)
+        try:
+            beam = DynamicEulerBernoulliBeam(path, force_params=ForceParams(**kw))
+        finally:
+            os.unlink(path)
+        out.update(df_arrays(name, beam.params))  # as parsed by the reference (see g34)
+        beam.create_system_func()
+        beam.create_input_func()
+        dyn = beam.get_dynamic_system()
+        n = beam.beam_model.M.shape[0]
+        x0 = np.zeros(2 * n)
+        if rand_x0:
+            # sigma_q=1e-5, sigma_v=1e-3 on free w/phi DOFs, axial 0
+            rng = np.random.default_rng(1234)
+            q = rng.normal(0.0, 1e-5, n)
+            v = rng.normal(0.0, 1e-3, n)
+            for i in range(n):
+                if beam.beam_model.dof_to_node_param[i][0] == "u":
+                    q[i] = 0.0
+                    v[i] = 0.0
+            x0 = np.concatenate([q, v])
+
+        def u_of_t(t, n=n, amp=amp):
+            u = np.zeros(n)
+            if t < 0.01:
+                u[-2] = amp
+            return u
+
+        xT, snaps = rk4(dyn, u_of_t, x0, 0.0, dt, max(cps), cps)
+        out[f"{name}/x0"] = x0
+        out[f"{name}/amp"] = np.float64(amp)
+        out[f"{name}/dt"] = np.float64(dt)
+        out[f"{name}/duration"] = np.float64(0.01)
+        out[f"{name}/checkpoints"] = np.array(cps, dtype=np.int32)
+        for c in cps:
+            out[f"{name}/x_{c}"] = snaps[c]
+            print(f"G5 {name}: tip w @{c} = {snaps[c][n - 2]!r}")
+        print(f"   ({time.time() - t_start:.1f} s)")
+    np.savez_compressed(os.path.join(HERE, "g5_rollouts.npz"), **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5"]
+    if "g1" in which:
+        g1_elements()
+    if "g2" in which:
+        g2_assembly()
+    if "g34" in which:
+        g34_forces_rhs()
+    if "g5" in which:
+        g5_rollouts()

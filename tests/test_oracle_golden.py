@@ -1,0 +1,141 @@
+"""Pin the CPU oracle (oracle/crb_oracle.c) to the reference's own outputs.
+
+The golden vectors were produced by tests/golden/make_golden.py importing the reference.
+Element/assembly/force quantities must agree to rounding (1e-12 rel); RHS and rollouts
+differ from the reference only by band-Cholesky-vs-explicit-inverse rounding
+(dynamic_beam_model.py:60), bounded here.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import beam_columns, force_kwargs, oracle_beam, rel_err
+
+G2_BEAMS = ["test4_lin", "test4_nl", "mixed5", "hetero7"]
+G2_SETS = ["none", "fixed0", "pinned0", "fixed0_pinned2", "pinned0_pinnedN"]
+G34_BEAMS = ["test4_lin", "test4_nl", "mixed5", "hetero7", "test4_nl_pinned0", "mixed5_fixed0_pinned2",
+             "hetero7_free", "hetero7_pinned0_fixed3"]
+FORCE_SETS = ["none", "drag", "grav", "both", "grav_xy", "both_xy"]
+
+
+def test_g1_element_matrices_and_nonlinear_force(golden):
+    from oracle import oracle as orc
+
+    z = golden["g1_elements"]
+    for m, (L, E, I, rho, A) in enumerate(z["materials"]):
+        assert rel_err(orc.elem_mass(L, rho, A), z["M_e"][m]) < 1e-15
+        assert rel_err(orc.elem_stiff_linear(L, E, I, A), z["K_e"][m]) < 1e-15
+        for s, x in enumerate(z["states"]):
+            f = orc.elem_force_nonlinear(L, E * A, E * I, x)
+            assert rel_err(f, z["f_nl"][m, s]) < 1e-13, (m, s)
+    # SURVEY §8(c) G1 anchor (tests/test_unified_beam_system.py:172 state, steel material)
+    anchor = [152294.66666666672, -369413.76342857233, 162711.4501904762, 253945.3333333333, 369413.76342857233,
+              209817.8978095231]
+    L, E, I, rho, A = z["materials"][0]
+    assert rel_err(orc.elem_force_nonlinear(L, E * A, E * I, z["states"][0]), anchor) < 1e-14
+
+
+@pytest.mark.parametrize("bname", G2_BEAMS)
+@pytest.mark.parametrize("sname", G2_SETS)
+def test_g2_assembly_and_boundary_reduction(golden, bname, sname):
+    z = golden["g2_assembly"]
+    key = f"{bname}/{sname}"
+    ob = oracle_beam(beam_columns(z, bname), node_bc=z[f"{key}/node_bc"])
+    M = z[f"{key}/M"]
+    assert ob.n == M.shape[0]
+    assert rel_err(ob.mass(), M) < 1e-15
+    full = ob.red2full()
+    assert np.array_equal(full % 3, z[f"{key}/dof_param"])
+    assert np.array_equal(full // 3, z[f"{key}/dof_node"])
+    constrained = sorted(set(range(ob.n_full)) - set(full.tolist()))
+    assert constrained == z[f"{key}/constrained"].tolist()
+    if f"{key}/K" in z.files:
+        assert rel_err(ob.stiffness(), z[f"{key}/K"]) < 1e-15
+    for q, k in zip(z[f"{key}/q"], z[f"{key}/k_q"]):
+        assert rel_err(ob.internal_force(q), k) < 1e-12
+    # band solve == dense solve
+    b = np.linspace(-1.0, 1.0, ob.n)
+    assert rel_err(ob.solve(b), np.linalg.solve(M, b)) < 1e-10
+
+
+@pytest.mark.parametrize("bname", G34_BEAMS)
+@pytest.mark.parametrize("fname", FORCE_SETS)
+def test_g3_g4_forces_and_rhs(golden, bname, fname):
+    z = golden["g34_forces_rhs"]
+    key = f"{bname}/{fname}"
+    ob = oracle_beam(beam_columns(z, bname), **force_kwargs(z, key))
+    X = z[f"{key}/x"]
+    n = ob.n
+    assert X.shape[1] == 2 * n
+    assert sorted(set(range(ob.n_full)) - set(ob.red2full().tolist())) == z[f"{key}/constrained"].tolist()
+    if f"{key}/FluidDragForce" in z.files:
+        pos, fac = ob.drag_table()
+        assert np.array_equal(pos, z[f"{key}/drag_w_pos_indices"])
+        assert np.array_equal(pos + n, z[f"{key}/drag_w_vel_indices"])
+        assert rel_err(fac, z[f"{key}/drag_factors"]) < 1e-15
+        for x, f in zip(X, z[f"{key}/FluidDragForce"]):
+            assert rel_err(ob.drag(x), f) < 1e-14
+    if f"{key}/GravityForce" in z.files:
+        for x, f in zip(X, z[f"{key}/GravityForce"]):
+            assert rel_err(ob.gravity(x), f) < 1e-14
+    for x, f in zip(X, z[f"{key}/f_total"]):
+        ref_scale = max(np.max(np.abs(f)), 1e-300)
+        assert np.max(np.abs(ob.forces(x) - f)) <= 1e-14 * ref_scale
+    if fname == "none":
+        Minv = z[f"{key}/M_inv"]
+        b = np.cos(np.arange(n))
+        assert rel_err(ob.solve(b), Minv @ b) < 1e-10
+    for i, x in enumerate(X):
+        for j, u in enumerate(z[f"{key}/u"]):
+            got = ob.rhs(x, u)
+            assert rel_err(got, z[f"{key}/xdot"][i, j]) < 1e-10, (i, j)
+
+
+G5 = ["lin10_grav", "lin64_grav", "lin64_grav_x0", "nl64_drag", "nl256_drag", "nl256_drag_a2", "mixed5_both",
+      "hetero7_both", "hetero7_p0f3_grav"]
+
+
+@pytest.mark.parametrize("name", G5)
+def test_g5_rk4_rollouts(golden, name):
+    z = golden["g5_rollouts"]
+    ob = oracle_beam(beam_columns(z, name), **force_kwargs(z, name))
+    x = z[f"{name}/x0"].copy()
+    dt, amp, dur = float(z[f"{name}/dt"]), float(z[f"{name}/amp"]), float(z[f"{name}/duration"])
+    done, t = 0, 0.0
+    for c in z[f"{name}/checkpoints"]:
+        if name == "lin10_grav" and c > 1000:
+            continue  # 5000-step leg is covered by the anchor test below (keeps the CPU suite short)
+        x = ob.rk4_impulse(x, dt, int(c) - done, amp, dur, -2, t0=t)
+        for _ in range(int(c) - done):
+            t = t + dt
+        done = int(c)
+        ref = z[f"{name}/x_{c}"]
+        # 1e-6 is north_star's bar; band-solve-vs-explicit-inverse rounding stays far below it
+        assert rel_err(x, ref) < 1e-8, (name, c, rel_err(x, ref))
+        assert abs(x[ob.n - 2] - ref[ob.n - 2]) <= 1e-9 * abs(ref[ob.n - 2])
+
+
+def test_g5_survey_anchors(golden):
+    """SURVEY.md §8(c) G5 anchors (tip w), measured there with the same accumulate-by-addition clock."""
+    z = golden["g5_rollouts"]
+    anchors = {("lin10_grav", 1000): -3.205454140232867e-03, ("lin10_grav", 5000): -7.253426908235e-02,
+               ("lin64_grav", 1000): -3.212364954272334e-03, ("nl64_drag", 200): 1.819829584899578e-05,
+               ("nl256_drag", 200): 1.819829584899578e-05, ("nl64_drag", 1000): 1.311443016e-04,
+               ("nl256_drag", 1000): 1.311443016e-04}
+    for (name, c), val in anchors.items():
+        x = z[f"{name}/x_{c}"]
+        n = x.size // 2
+        assert abs(x[n - 2] - val) <= 2e-9 * abs(val), (name, c, x[n - 2], val)
+    ob = oracle_beam(beam_columns(z, "lin10_grav"), **force_kwargs(z, "lin10_grav"))
+    x = ob.rk4_impulse(z["lin10_grav/x0"], 2e-5, 5000, 0.1)
+    assert abs(x[ob.n - 2] - (-7.253426908235e-02)) <= 1e-9 * 7.25e-2
+
+
+def test_batch_matches_single():
+    from tests.helpers import nitinol_columns
+
+    ob = oracle_beam(nitinol_columns(12, "nonlinear"), fluid_density=1000.0, enable_fluid=True)
+    amps = 0.1 * (1.0 + np.arange(5) / 5.0)
+    X, used = ob.rk4_impulse_batch(np.zeros((5, 2 * ob.n)), 2e-5, 50, amps, n_threads=2)
+    assert used == 2
+    for b in range(5):
+        assert np.array_equal(X[b], ob.rk4_impulse(np.zeros(2 * ob.n), 2e-5, 50, amps[b]))
