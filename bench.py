@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- beam-element-steps/s of the fused RK4 beam stepper on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one classical RK4 time step (dt = 2e-5 s) of the whole batch.  Workload at N = 1 is
+BASELINE.json's metric configuration (configs[2]): 4096 beams x 256 nonlinear Euler-Bernoulli
+elements + fluid drag (Nitinol constants of examples/example_utilities.py:25-34, FIXED at node 0,
+zero initial state, per-beam tip impulse 0.1*(1 + b/B) N for t < 0.01 s), fp64.  With N > 1 every
+rank owns 4096 beams of the 4096*N ensemble (independent units, weak scaling, no per-step
+communication) and the terminal states are all-gathered over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit, ms_per_step,
+`roofline` (algorithmic HBM bytes = 96 B per element-step) and `cpu_baseline`
+(the C oracle -- a port of the reference path -- on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "continuum-robot_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_VALU_PEAK_TF = 78.6       # public MI355X vector fp64 figure
+BYTES_PER_ELEM_STEP = {torch.float64: 96.0, torch.float32: 48.0}
+FLOP_PER_ELEM_STEP = {"nonlinear": 1.9e3, "linear": 1.0e3}  # SURVEY §8(d) algorithmic estimate
+
+CONFIGS = {
+    # name: (beams per GPU, elements, element type, force kwargs, random x0, default steps)
+    "config3": dict(beams=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False,
+                    label="4096 beams x 256 elem, nonlinear Euler-Bernoulli + fluid drag, fp64"),
+    "config2": dict(beams=1024, elems=64, kind="linear", drag=False, gravity=True, x0=True,
+                    label="1024 beams x 64 elem, linear + gravity, fp64"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--launch-steps", type=int, default=0, help="RK4 steps fused per launch (0 = all of --steps)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cols, kw, n_elem, target_s=15.0):
+    """Time the C oracle (port of the reference path) on this box's host cores, bounded sample."""
+    from tests.helpers import oracle_beam
+
+    ob = oracle_beam(cols, **kw)
+    cores = os.cpu_count() or 1
+    # calibrate on one beam, then size the sample for ~target_s of wall time on all cores
+    t0 = time.perf_counter()
+    ob.rk4_impulse(np.zeros(2 * ob.n), 2e-5, 20, 0.1)
+    per_beam_step = (time.perf_counter() - t0) / 20
+    steps = 200
+    beams = int(max(cores, min(4096, target_s * cores / (per_beam_step * steps))))
+    beams = (beams // cores) * cores or cores
+    amps = 0.1 * (1.0 + np.arange(beams) / beams)
+    t0 = time.perf_counter()
+    _, used = ob.rk4_impulse_batch(np.zeros((beams, 2 * ob.n)), 2e-5, steps, amps, n_threads=cores)
+    wall = time.perf_counter() - t0
+    return {"value": beams * n_elem * steps / wall, "unit": "beam-element-steps/s", "cores": int(used), "kind": "port",
+            "sample": f"{beams} beams x {n_elem} elem x {steps} RK4 steps, C oracle (oracle/crb_oracle.c), "
+                      f"OpenMP over beams, {wall:.1f} s wall",
+            "reference_python_1core": 3796.0}  # BASELINE.md §2, measured in the survey container
+
+
+def main():
+    args = parse()
+    cfg = CONFIGS[args.config]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the stepper has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from continuum_robot.batched import BeamEnsemble
+    from continuum_robot.models.force_params import ForceParams
+    from tests.helpers import nitinol_columns, oracle_beam, rel_err
+
+    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    B, ne = cfg["beams"], cfg["elems"]
+    B_total = B * world
+    cols = nitinol_columns(ne, cfg["kind"])
+    fp = ForceParams(fluid_density=1000.0 if cfg["drag"] else 0.0, enable_fluid_effects=cfg["drag"],
+                     enable_gravity_effects=cfg["gravity"])
+    okw = dict(fluid_density=fp.fluid_density, enable_fluid=cfg["drag"], enable_gravity=cfg["gravity"])
+    t_plan = time.perf_counter()
+    ens = BeamEnsemble(cols, B, force_params=fp, dtype=dtype, device=f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+    plan_ms = (time.perf_counter() - t_plan) * 1e3
+
+    gidx = rank * B + np.arange(B)
+    amps = torch.as_tensor(0.1 * (1.0 + gidx / B_total), dtype=dtype, device=ens.device)
+    x0 = None
+    if cfg["x0"]:
+        rng = np.random.default_rng(1234 + rank)
+        n = ens.n
+        x0n = np.concatenate([rng.normal(0, 1e-5, (B, n)), rng.normal(0, 1e-3, (B, n))], axis=1)
+        x0n[:, 0:n:3] = 0.0
+        x0n[:, n::3] = 0.0
+        x0 = ens.pack_state(x0n)
+
+    def reset():
+        if x0 is None:
+            ens.zero_state()
+        else:
+            ens.state.copy_(x0)
+            ens.time = 0.0
+
+    dt = 2e-5
+    per_launch = args.launch_steps if args.launch_steps > 0 else args.steps
+    # ---- warmup (untimed), then restore the initial state so the timed K steps are the
+    # parity-checked trajectory (the shipped nonlinear element is only stable to ~1000 steps)
+    reset()
+    if args.warmup > 0:
+        ens.step(args.warmup, dt, impulse_amp=amps)
+    reset()
+    gathered = torch.empty((world,) + tuple(ens.state.shape), dtype=dtype, device=ens.device) if world > 1 else None
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+
+    events = []
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    done = 0
+    while done < args.steps:
+        k = min(per_launch, args.steps - done)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ens.step(k, dt, impulse_amp=amps)
+        e1.record()
+        events.append((e0, e1, k))
+        done += k
+    if dist:
+        dist.all_gather_into_tensor(gathered, ens.state)  # the one exchange: terminal states
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.perf_counter() - t_start
+    if dist:
+        tmax = torch.tensor([wall], dtype=torch.float64, device=ens.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+    full = [ms for (ms, (_, _, k)) in zip(kernel_ms, events) if k == per_launch] or kernel_ms
+    avg_launch_s = float(np.mean(full)) * 1e-3
+    algo_bytes_launch = BYTES_PER_ELEM_STEP[dtype] * B * ne * min(per_launch, args.steps)
+    achieved = algo_bytes_launch / avg_launch_s / 1e9
+
+    # ---- sanity / parity of what was just timed (after the clock stopped)
+    state = ens.unpack_state()
+    finite = bool(torch.isfinite(state).all())
+    check = {"finite": finite}
+    if rank == 0:
+        ob = oracle_beam(cols, **okw)
+        b = B - 1
+        ref = ob.rk4_impulse(np.zeros(2 * ob.n) if x0 is None else x0n[b], dt, args.steps, float(amps[b].item()))
+        check["rel_err_vs_oracle_last_beam"] = rel_err(state[b].double().cpu().numpy(), ref)
+        check["tip_w_last_beam"] = float(state[b, ens.n - 2].item())
+
+    if rank == 0:
+        value = B_total * ne * args.steps / wall
+        out = {
+            "metric": "beam-element-steps/s",
+            "value": value,
+            "unit": "beam-element-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": cfg["label"], "beams_per_gpu": B, "beams_total": B_total, "elements": ne,
+                       "dt": dt, "steps_per_launch": min(per_launch, args.steps), "parallelism": f"beam-shard x{world}",
+                       "collective": "all_gather_into_tensor(terminal states)" if world > 1 else "none",
+                       "plan_ms": plan_ms},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "crb_beam_kernel<MODE_STEP>", "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "valu_fp64_frac_estimate": (FLOP_PER_ELEM_STEP[cfg["kind"]] * B * ne
+                                                     * min(per_launch, args.steps) / avg_launch_s / 1e12)
+                         / FP64_VALU_PEAK_TF if dtype == torch.float64 else None},
+            "check": check,
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            try:
+                tj = json.load(open(traffic_file))
+                key = f"{args.config}:{args.dtype}:{min(per_launch, args.steps)}"
+                if key in tj:
+                    out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = tj[key].get("source")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cols, okw, ne)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build the HIP extension first (make -C continuum-robot_amd, or "
             "__graft_entry__.build()).  The beam stepper has no CPU fallback.")
+    # libcrbeam.so needs libamdhip64.so.7.  PyTorch-ROCm bundles its own copy under the same
+    # SONAME, and the process must hold exactly ONE HIP runtime (device pointers and streams come
+    # from torch): import torch first so that its runtime is the one both sides resolve to.
+    import torch  # noqa: F401
+
+    torch_hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(torch_hip):
+        C.CDLL(torch_hip, mode=C.RTLD_GLOBAL)
     L = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int
     L.crb_version.restype = i32

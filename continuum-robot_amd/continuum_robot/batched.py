@@ -1,0 +1,205 @@
+"""BeamEnsemble -- B independent beams of one topology stepped on an MI355X.
+
+This is the batched entry point of the drop-in: it owns the state tensor
+``[B, 2, n_node, 4]`` on the GPU (PyTorch-ROCm memory) and calls the HIP kernels of libcrbeam.so
+through the C ABI (include/crbeam.h).  The planning / control layers hold one ensemble per robot
+model and roll it out; nothing here runs on the CPU -- without the extension or a GPU every
+operation raises.
+
+Reference interfaces mirrored (file:line under /root/reference/src/continuum_robot/models/):
+  constructor arguments   dynamic_beam_model.py:25-29 (CSV schema :78-90, ForceParams)
+  rhs()                   get_dynamic_system()(t, x, u), dynamic_beam_model.py:343-362
+  internal_force()        get_stiffness_function(), euler_bernoulli_beam.py:364-368
+  step()                  the scipy.solve_ivp call sites (examples/example_utilities.py:153-159)
+"""
+import ctypes as C
+import pathlib
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import _native as nat
+from .models.force_params import ForceParams
+
+_CSV_REQUIRED = ["length", "elastic_modulus", "moment_inertia", "density", "cross_area", "type", "boundary_condition"]
+_PARAM = {"u": 0, "w": 1, "phi": 2}
+
+
+def _columns(parameters, need_fluid):
+    if isinstance(parameters, (str, pathlib.Path)):
+        parameters = pd.read_csv(parameters)  # FileNotFoundError propagates, as in the reference (:46)
+    if isinstance(parameters, pd.DataFrame):
+        cols = {c: parameters[c].to_numpy() for c in parameters.columns}
+    elif isinstance(parameters, dict):
+        cols = dict(parameters)
+    else:
+        raise TypeError("Parameters must be filepath, pandas DataFrame or a dict of columns")
+    required = _CSV_REQUIRED + (["wetted_area", "drag_coef"] if need_fluid else [])
+    if not all(c in cols for c in required):
+        raise ValueError(f"CSV must contain columns: {', '.join(required)}")
+    bad = set(str(b) for b in cols["boundary_condition"]) - {"FIXED", "PINNED", "NONE"}
+    if bad:
+        raise ValueError(f"Invalid boundary conditions: {bad}")
+    return cols
+
+
+class BeamEnsemble:
+    def __init__(self, parameters, n_beams: int, force_params: Optional[ForceParams] = None, dtype=torch.float64,
+                 device: Union[str, torch.device, int] = "cuda", corrected_axial: bool = False, node_bc=None):
+        self.force_params = force_params or ForceParams()
+        fp = self.force_params
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        nat.load()  # raises if the extension was not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("BeamEnsemble needs a HIP device: the beam stepper has no CPU path")
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise RuntimeError("BeamEnsemble needs a HIP device: the beam stepper has no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.dtype = dtype
+        self.columns = _columns(parameters, fp.enable_fluid_effects)
+        self.plan = nat.Plan(self.columns, n_beams=n_beams, node_bc=node_bc, fluid_density=fp.fluid_density,
+                             enable_fluid=fp.enable_fluid_effects, gravity=fp.get_gravity_vector(),
+                             enable_gravity=fp.enable_gravity_effects, corrected_axial=corrected_axial,
+                             dtype="f64" if dtype == torch.float64 else "f32", device=self.device.index)
+        p = self.plan
+        self.n_beams, self.n_elem, self.n_node, self.n = n_beams, p.n_elem, p.n_node, p.n_free
+        self.free_index = p.free_index.copy()
+        self.state = torch.zeros((n_beams, 2, self.n_node, 4), dtype=dtype, device=self.device)
+        self.time = 0.0
+        self._lib = nat.load()
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, shape=None):
+        t = torch.as_tensor(a, dtype=self.dtype, device=self.device).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def reduced_index(self, node: int, param: str) -> int:
+        """Reduced position index of (node, 'u'|'w'|'phi'); KeyError when constrained or absent
+        (reference: EulerBernoulliBeam.get_dof_index, euler_bernoulli_beam.py:404-420)."""
+        full = 3 * node + _PARAM[param]
+        hit = np.nonzero(self.free_index == full)[0]
+        if node < 0 or node >= self.n_node or hit.size == 0:
+            raise KeyError(f"Invalid node/parameter combination: ({node}, {param})")
+        return int(hit[0])
+
+    # ------------------------------------------------------------------ layout conversion
+    def pack_state(self, x_red) -> torch.Tensor:
+        """reduced [B, 2n] (reference ordering [q_red ; v_red]) -> device layout [B, 2, n_node, 4]"""
+        x_red = self._dev(x_red, (self.n_beams, 2 * self.n))
+        out = torch.empty_like(self.state)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_pack_state(self.plan.h, self._ptr(x_red), self._ptr(out), self._stream()))
+        return out
+
+    def unpack_state(self, x=None) -> torch.Tensor:
+        x = self.state if x is None else x
+        out = torch.empty((self.n_beams, 2 * self.n), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_unpack_state(self.plan.h, self._ptr(x), self._ptr(out), self._stream()))
+        return out
+
+    def pack_vec(self, v_red) -> torch.Tensor:
+        v_red = self._dev(v_red, (self.n_beams, self.n))
+        out = torch.empty((self.n_beams, self.n_node, 4), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_pack_vec(self.plan.h, self._ptr(v_red), self._ptr(out), self._stream()))
+        return out
+
+    def unpack_vec(self, v) -> torch.Tensor:
+        out = torch.empty((self.n_beams, self.n), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_unpack_vec(self.plan.h, self._ptr(v), self._ptr(out), self._stream()))
+        return out
+
+    def set_state(self, x_red, time: float = 0.0) -> None:
+        self.state = self.pack_state(x_red)
+        self.time = float(time)
+
+    def zero_state(self) -> None:
+        self.state.zero_()
+        self.time = 0.0
+
+    # ------------------------------------------------------------------ the hot path
+    def internal_force(self, q_red) -> torch.Tensor:
+        """k(q) for every beam, reduced [B, n]."""
+        q = self._dev(q_red, (self.n_beams, self.n))
+        x = self.pack_state(torch.cat([q, torch.zeros_like(q)], dim=1))
+        k = torch.empty((self.n_beams, self.n_node, 4), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_internal_force(self.plan.h, self._ptr(x), self._ptr(k), self._stream()))
+        return self.unpack_vec(k)
+
+    def rhs_device(self, x: torch.Tensor, u: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """xdot in device layout for a state (and optional force) in device layout."""
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_rhs(self.plan.h, self._ptr(x), self._ptr(u), self._ptr(out), self._stream()))
+        return out
+
+    def rhs(self, x_red=None, u_red=None) -> torch.Tensor:
+        """dynamic_system(t, x, u) for every beam: reduced [B, 2n] in, reduced [B, 2n] out."""
+        x = self.state if x_red is None else self.pack_state(x_red)
+        u = None if u_red is None else self.pack_vec(u_red)
+        return self.unpack_state(self.rhs_device(x, u))
+
+    def step(self, n_steps: int, dt: float, impulse_amp=None, impulse_duration: float = 0.01,
+             impulse_index: int = -2, held_force=None, t0: Optional[float] = None) -> float:
+        """Advance the resident state by ``n_steps`` RK4 steps in one kernel launch.
+
+        impulse_amp    per-beam amplitudes [B] of the examples' forcing: that value on reduced
+                       position index ``impulse_index`` (-2 = tip w, example_utilities.py:147)
+                       while t < impulse_duration
+        held_force     reduced [B, n] generalised force held constant over the call
+        Returns the clock after the call (accumulated by addition, as the oracle does).
+        """
+        if t0 is not None:
+            self.time = float(t0)
+        desc = nat.InputDesc()
+        desc.kind = nat.CRB_INPUT_NONE
+        keep = []
+        if impulse_amp is not None:
+            amp = self._dev(impulse_amp, (self.n_beams,))
+            idx = impulse_index if impulse_index >= 0 else self.n + impulse_index
+            if not 0 <= idx < self.n:
+                raise IndexError("impulse_index out of range")
+            full = int(self.free_index[idx])
+            desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, full // 3, full % 3
+            desc.duration = float(impulse_duration)
+            desc.amp = amp.data_ptr()
+            keep.append(amp)
+        if held_force is not None:
+            held = self.pack_vec(held_force)
+            desc.f_held = held.data_ptr()
+            keep.append(held)
+        t_end = C.c_double(0.0)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_step_rk4(self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps),
+                                             C.byref(desc), C.byref(t_end), self._stream()))
+        self._keep = keep  # device buffers must outlive the asynchronous launch
+        self.time = t_end.value
+        return self.time
+
+    def gather(self, node: int, param: str, velocity: bool = False) -> torch.Tensor:
+        out = torch.empty((self.n_beams,), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_gather_dof(self.plan.h, self._ptr(self.state), int(velocity), int(node),
+                                               _PARAM[param], self._ptr(out), self._stream()))
+        return out
+
+    def tip_displacement(self) -> torch.Tensor:
+        """w of the last node for every beam (the examples' 'tip displacement', lqr_control.py:168)."""
+        return self.gather(self.n_elem, "w")

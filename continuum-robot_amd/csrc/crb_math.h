@@ -296,7 +296,7 @@ CRB_HD void pcr_factor_level(const NodeBlocks& me, const NodeBlocks& lo, bool ha
 
 // Size of a level's multipliers relative to 1, with the rotation DOF scaled by a
 // characteristic length Lc so that force/moment units compare (used to decide how many
-// levels the solve needs: below ~2^-60 a level no longer changes an fp64 result).
+// levels the solve needs: below the unit roundoff 2^-53 a level no longer changes an fp64 result).
 CRB_HD double pcr_level_norm(const PcrLevel& lv, double Lc) {
     double m = fabs(lv.al_ax);
     const double v[9] = {fabs(lv.ga_ax),       fabs(lv.al[0]),      fabs(lv.al[1]) * Lc, fabs(lv.al[2]) / Lc, fabs(lv.al[3]),

@@ -265,7 +265,9 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
         cur.swap(nxt);
         states.push_back(cur);
     }
-    const double tol = (dtype == CRB_F64) ? std::ldexp(1.0, -60) : std::ldexp(1.0, -30);
+    // a level whose multipliers are below the unit roundoff of the plan dtype cannot change a
+    // result by more than half an ulp: the reduction stops there (exact to rounding)
+    const double tol = (dtype == CRB_F64) ? std::ldexp(1.0, -53) : std::ldexp(1.0, -24);
     int used = lf;
     while (used > 0 && p->h_norms[used - 1] < tol) --used;
     p->levels = used;

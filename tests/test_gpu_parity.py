@@ -1,0 +1,262 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via BeamEnsemble) against
+  (1) the golden vectors generated from the reference itself (tests/golden/*.npz), and
+  (2) the CPU oracle on the same seeded inputs,
+plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerances: north_star asks 1e-6 relative fp64; the HIP path and the reference differ only
+by rounding (cyclic-reduction solve vs explicit inverse, regrouped polynomial, FMA contraction), so
+the fp64 assertions are far tighter and written next to each check.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import beam_columns, force_kwargs, nitinol_columns, oracle_beam, rel_err
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def ensemble(cols, n_beams, kw=None, dtype=None, node_bc=None, corrected_axial=False):
+    from continuum_robot.batched import BeamEnsemble
+    from continuum_robot.models.force_params import ForceParams
+
+    kw = kw or {}
+    fp = ForceParams(fluid_density=kw.get("fluid_density", 0.0), enable_fluid_effects=kw.get("enable_fluid", False),
+                     gravity_vector=list(kw.get("gravity", [0.0, -9.81, 0.0])),
+                     enable_gravity_effects=kw.get("enable_gravity", False))
+    return BeamEnsemble(cols, n_beams, force_params=fp, dtype=dtype or torch.float64, node_bc=node_bc,
+                        corrected_axial=corrected_axial)
+
+
+def test_native_library_is_the_loaded_path():
+    from continuum_robot import _native as nat
+
+    assert nat.load().crb_version() == 100
+    assert torch.cuda.is_available()
+
+
+G2_BEAMS = ["test4_lin", "test4_nl", "mixed5", "hetero7"]
+G2_SETS = ["none", "fixed0", "pinned0", "fixed0_pinned2", "pinned0_pinnedN"]
+
+
+@pytest.mark.parametrize("bname", G2_BEAMS)
+@pytest.mark.parametrize("sname", G2_SETS)
+def test_internal_force_matches_reference(golden, bname, sname):
+    z = golden["g2_assembly"]
+    key = f"{bname}/{sname}"
+    q, k = z[f"{key}/q"], z[f"{key}/k_q"]
+    ens = ensemble(beam_columns(z, bname), q.shape[0], node_bc=z[f"{key}/node_bc"].astype(np.uint8))
+    got = ens.internal_force(q).cpu().numpy()
+    assert rel_err(got, k) < 1e-12
+
+
+G34_BEAMS = ["test4_lin", "test4_nl", "mixed5", "hetero7", "test4_nl_pinned0", "mixed5_fixed0_pinned2",
+             "hetero7_free", "hetero7_pinned0_fixed3"]
+FORCE_SETS = ["none", "drag", "grav", "both", "grav_xy", "both_xy"]
+
+
+@pytest.mark.parametrize("bname", G34_BEAMS)
+@pytest.mark.parametrize("fname", FORCE_SETS)
+def test_rhs_matches_reference(golden, bname, fname):
+    """dynamic_system(t, x, u) on the reference's own outputs: every (state, input) pair is one beam."""
+    z = golden["g34_forces_rhs"]
+    key = f"{bname}/{fname}"
+    X, U, ref = z[f"{key}/x"], z[f"{key}/u"], z[f"{key}/xdot"]
+    xs = np.repeat(X, U.shape[0], axis=0)
+    us = np.tile(U, (X.shape[0], 1))
+    ens = ensemble(beam_columns(z, bname), xs.shape[0], force_kwargs(z, key))
+    got = ens.rhs(xs, us).cpu().numpy().reshape(ref.shape)
+    assert rel_err(got, ref) < 1e-10
+    # u = None is the zero input (first row of U)
+    got0 = ens.rhs(xs).cpu().numpy().reshape(ref.shape)
+    assert rel_err(got0[:, 0], ref[:, 0]) < 1e-10
+
+
+G5 = ["lin10_grav", "lin64_grav", "lin64_grav_x0", "nl64_drag", "nl256_drag", "nl256_drag_a2", "mixed5_both",
+      "hetero7_both", "hetero7_p0f3_grav"]
+
+
+@pytest.mark.parametrize("name", G5)
+def test_rk4_rollouts_match_reference(golden, name):
+    """Fused multi-step RK4 against RK4 over the reference's own RHS (tests/golden/make_golden.py)."""
+    z = golden["g5_rollouts"]
+    B = 3  # identical beams: also checks that beams of a workgroup do not interact
+    ens = ensemble(beam_columns(z, name), B, force_kwargs(z, name))
+    n = ens.n
+    ens.set_state(np.tile(z[f"{name}/x0"], (B, 1)))
+    dt, amp, dur = float(z[f"{name}/dt"]), float(z[f"{name}/amp"]), float(z[f"{name}/duration"])
+    done = 0
+    for c in z[f"{name}/checkpoints"]:
+        ens.step(int(c) - done, dt, impulse_amp=np.full(B, amp), impulse_duration=dur, impulse_index=-2)
+        done = int(c)
+        got = ens.unpack_state().cpu().numpy()
+        ref = z[f"{name}/x_{c}"]
+        err = rel_err(got[0], ref)
+        assert err < 1e-8, (name, c, err)  # bar: 1e-6 (north_star)
+        assert abs(got[0, n - 2] - ref[n - 2]) <= 1e-9 * abs(ref[n - 2])  # tip displacement
+        assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+
+
+def test_batched_rollout_matches_oracle_per_beam():
+    """64 nonlinear + drag beams with distinct impulse amplitudes, zero initial state."""
+    cols = nitinol_columns(64, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    B, steps, dt = 64, 200, 2e-5
+    amps = 0.1 * (1.0 + np.arange(B) / B)
+    ens = ensemble(cols, B, kw)
+    ens.step(steps, dt, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    ob = oracle_beam(cols, **kw)
+    ref, _ = ob.rk4_impulse_batch(np.zeros((B, 2 * ob.n)), dt, steps, amps)
+    assert rel_err(got, ref) < 1e-9
+    tips = ens.tip_displacement().cpu().numpy()
+    assert np.allclose(tips, ref[:, ob.n - 2], rtol=1e-9, atol=0)
+    assert np.all(np.diff(tips) > 0)  # larger impulse, larger tip displacement
+
+
+def test_linear_gravity_ensemble_with_random_initial_states_matches_oracle():
+    """BASELINE config 2 in small: per-beam x0 ~ N(0, sigma) on w/phi DOFs."""
+    cols = nitinol_columns(64, "linear")
+    kw = dict(enable_gravity=True)
+    B, steps, dt = 32, 300, 2e-5
+    ob = oracle_beam(cols, **kw)
+    n = ob.n
+    rng = np.random.default_rng(1234)
+    x0 = np.concatenate([rng.normal(0, 1e-5, (B, n)), rng.normal(0, 1e-3, (B, n))], axis=1)
+    x0[:, 0:n:3] = 0.0
+    x0[:, n::3] = 0.0
+    amps = 0.1 * (1.0 + np.arange(B) / B)
+    ens = ensemble(cols, B, kw)
+    ens.set_state(x0)
+    ens.step(steps, dt, impulse_amp=amps)
+    ref, _ = ob.rk4_impulse_batch(x0, dt, steps, amps)
+    assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
+
+
+def test_chunked_launches_are_bitwise_identical_to_one_launch():
+    cols = nitinol_columns(32, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True)
+    amps = np.linspace(0.05, 0.2, 7)
+    a = ensemble(cols, 7, kw)
+    b = ensemble(cols, 7, kw)
+    a.step(600, 2e-5, impulse_amp=amps)
+    for chunk in (1, 99, 400, 100):  # crosses the t < 0.01 switch-off at step 500
+        b.step(chunk, 2e-5, impulse_amp=amps)
+    assert a.time == b.time
+    assert torch.equal(a.state, b.state)
+
+
+def test_held_force_and_pack_roundtrip():
+    cols = nitinol_columns(12, "linear")
+    ob = oracle_beam(cols)
+    n, B = ob.n, 5
+    rng = np.random.default_rng(9)
+    x0 = rng.normal(0, 1e-4, (B, 2 * n))
+    u = rng.normal(0, 0.05, (B, n))
+    ens = ensemble(cols, B)
+    ens.set_state(x0)
+    assert np.array_equal(ens.unpack_state().cpu().numpy(), x0)
+    assert float(ens.state[..., 3].abs().max()) == 0.0 and float(ens.state[:, :, 0].abs().max()) == 0.0
+    ens.step(150, 2e-5, held_force=u)
+    ref = np.array([ob.rk4_held(x0[b], 2e-5, 150, u[b]) for b in range(B)])
+    assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-10
+
+
+@pytest.mark.parametrize("n_e,B", [(1, 1), (2, 70), (10, 13), (63, 5), (65, 3), (130, 2), (300, 2)])
+def test_ragged_sizes_and_partial_groups(n_e, B):
+    """Beam sizes around the wavefront/workgroup boundaries, batch sizes that leave a group partly empty."""
+    kinds = ["nonlinear" if i % 2 else "linear" for i in range(n_e)]
+    cols = nitinol_columns(n_e, kinds)
+    kw = dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True, gravity=[1.0, -9.81, 0.0])
+    ob = oracle_beam(cols, **kw)
+    amps = 0.05 * (1.0 + np.arange(B))
+    ens = ensemble(cols, B, kw)
+    ens.step(120, 2e-5, impulse_amp=amps)
+    ref, _ = ob.rk4_impulse_batch(np.zeros((B, 2 * ob.n)), 2e-5, 120, amps)
+    assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
+
+
+def test_corrected_axial_option_matches_oracle():
+    cols = nitinol_columns(16, "nonlinear")
+    ob = oracle_beam(cols, corrected_axial=True)
+    ens = ensemble(cols, 2, corrected_axial=True)
+    ens.step(200, 2e-5, impulse_amp=np.array([0.1, 0.3]))
+    ref, _ = ob.rk4_impulse_batch(np.zeros((2, 2 * ob.n)), 2e-5, 200, np.array([0.1, 0.3]))
+    assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
+
+
+def test_fp32_plan_tracks_fp64_within_measured_drift():
+    """BASELINE config 4's dtype.  fp32 is NOT held to 1e-6: cond(M) ~ 1e4 costs ~4 digits
+    (SURVEY §7); the tolerance here is the measured drift with margin, over the 200-step horizon."""
+    cols = nitinol_columns(256, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    amps = np.array([0.1, 0.15, 0.2])
+    e64 = ensemble(cols, 3, kw)
+    e32 = ensemble(cols, 3, kw, dtype=torch.float32)
+    e64.step(200, 2e-5, impulse_amp=amps)
+    e32.step(200, 2e-5, impulse_amp=amps)
+    t64, t32 = e64.tip_displacement().cpu().numpy(), e32.tip_displacement().double().cpu().numpy()
+    assert np.all(np.isfinite(t32))
+    assert np.max(np.abs(t32 - t64) / np.abs(t64)) < 5e-3
+
+
+def test_full_size_config3_properties():
+    """4096 beams x 256 nonlinear elements + drag (BASELINE config 3), 100 steps:
+    (a) beams with equal input are bitwise equal wherever they sit in the grid,
+    (b) tip displacement is monotone in the impulse amplitude,
+    (c) the first / middle / last beam match the oracle."""
+    cols = nitinol_columns(256, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    B, steps, dt = 4096, 100, 2e-5
+    amps = 0.1 * (1.0 + np.arange(B) / B)
+    amps[1::512] = amps[0]  # replicas of beam 0 scattered over the grid
+    ens = ensemble(cols, B, kw)
+    ens.step(steps, dt, impulse_amp=amps)
+    x = ens.unpack_state()
+    assert bool(torch.isfinite(x).all())
+    for b in range(1, B, 512):
+        assert torch.equal(x[b], x[0])
+    tips = ens.tip_displacement().cpu().numpy()
+    order = np.argsort(amps, kind="stable")
+    assert np.all(np.diff(tips[order]) >= 0)
+    ob = oracle_beam(cols, **kw)
+    for b in (0, B // 2, B - 1):
+        ref = ob.rk4_impulse(np.zeros(2 * ob.n), dt, steps, amps[b])
+        assert rel_err(x[b].cpu().numpy(), ref) < 1e-9
+
+
+def test_full_size_config2_against_oracle_sample():
+    """1024 beams x 64 linear elements + gravity (BASELINE config 2), random x0, 200 steps."""
+    cols = nitinol_columns(64, "linear")
+    kw = dict(enable_gravity=True)
+    B, steps, dt = 1024, 200, 2e-5
+    ob = oracle_beam(cols, **kw)
+    n = ob.n
+    rng = np.random.default_rng(1234)
+    x0 = np.concatenate([rng.normal(0, 1e-5, (B, n)), rng.normal(0, 1e-3, (B, n))], axis=1)
+    x0[:, 0:n:3] = 0.0
+    x0[:, n::3] = 0.0
+    amps = 0.1 * (1.0 + np.arange(B) / B)
+    ens = ensemble(cols, B, kw)
+    ens.set_state(x0)
+    ens.step(steps, dt, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    sel = np.arange(0, B, 37)
+    ref, _ = ob.rk4_impulse_batch(x0[sel], dt, steps, amps[sel])
+    assert rel_err(got[sel], ref) < 1e-9
+
+
+def test_error_paths():
+    from continuum_robot import _native as nat
+
+    cols = nitinol_columns(4, "linear")
+    ens = ensemble(cols, 2)
+    with pytest.raises(ValueError):
+        ens.set_state(np.zeros((2, 5)))
+    with pytest.raises(IndexError):
+        ens.step(1, 2e-5, impulse_amp=np.ones(2), impulse_index=ens.n)
+    with pytest.raises(nat.NativeError, match="dt must be positive"):
+        ens.step(1, 0.0)
+    with pytest.raises(ValueError, match="CSV must contain columns"):
+        ensemble({k: v for k, v in cols.items() if k != "density"}, 1)

@@ -274,13 +274,13 @@ def test_plan_tables_reproduce_reference_rhs(golden, bname, fname):
 
 
 def test_truncated_reduction_is_exact_to_rounding_on_long_beams():
-    """n_e = 256 cantilever: levels beyond the kept ones have multipliers < 2^-60."""
+    """n_e = 256 cantilever: levels beyond the kept ones have multipliers below the unit roundoff."""
     cols = nitinol_columns(256, "nonlinear")
     plan = host_plan(cols)
     assert (plan.n_slots, plan.node_offset, plan.threads, plan.beams_per_group) == (256, 1, 256, 1)
     levels, final, norms = plan.pcr_tables()
     assert plan.pcr_levels_full == 8 and 4 <= plan.pcr_levels <= 6
-    assert np.all(norms[plan.pcr_levels:] < 2.0**-60)
+    assert np.all(norms[plan.pcr_levels:] < 2.0**-53)
     ob = oracle_beam(cols)
     model = SlotModel(plan, cols)
     b = np.random.default_rng(3).normal(size=plan.n_free)
