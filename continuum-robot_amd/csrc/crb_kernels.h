@@ -1,13 +1,25 @@
 // crb_kernels.h -- gfx950 kernels of the beam stepper (included once by crbeam.hip).
 //
-// Decomposition: one thread per node ("slot") of a beam, G = threads / n_slots
-// beams per workgroup.  A thread keeps its node's state (3 positions, 3 velocities), the RK4
-// accumulators and its element/force coefficients in registers for the whole launch; the only
-// HBM traffic of crb_step_rk4 is one read and one write of the state per LAUNCH.  Neighbour
-// data moves through LDS (SoA, conflict-free 8-byte accesses):
-//   q of the left node      -> element force of the element left of the node
-//   element force halves    -> nodal internal force (no atomics: each node sums exactly two)
-//   gravity per segment     -> index table (reduced-index quirk of gravity_forces.py:104-146)
+// Decomposition: one thread per node ("slot") of a beam.  A thread keeps, in
+// registers and for the whole launch: its node's state (3 positions, 3 velocities), the RK4
+// accumulators, its element / force coefficients AND its rows of the cyclic-reduction
+// multipliers of the mass matrix.  crb_step_rk4 therefore touches HBM once per LAUNCH (state in,
+// state out) and nothing else: no coefficient stream, no per-step traffic.
+//
+// Slot -> thread map.  A beam with S >= 64 slots owns a whole workgroup of NW = NT/64
+// wavefronts and slot j lives in wave (j % NW), lane (j / NW).  A cyclic-reduction level of
+// stride s = 2^l then needs
+//     l >= log2(NW) : the value of lane +/- s/NW of the SAME wave  -> ds_bpermute, no barrier
+//     l <  log2(NW) : a value of another wave                      -> LDS + one s_barrier
+// so a 256-slot beam (NW = 4) pays barriers only for strides 1 and 2.  LDS is indexed by thread
+// id (conflict-free 8-byte accesses); the thread holding slot j is  (j % NW)*64 + j / NW.
+// Beams with S < 64 slots pack G = 64/S beams into one wave (thread = g*S + j) and never need
+// a barrier for the solve.
+//
+// Neighbour traffic per RHS evaluation:
+//   q of the left node      -> element force of the element left of the node        (stride 1)
+//   element force halves    -> nodal internal force; each node sums exactly two     (stride 1)
+//   gravity per segment     -> index table (reduced-index quirk, gravity_forces.py:104-146)
 //   r at distance 2^l       -> parallel cyclic reduction for Minv (precomputed multipliers)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -44,6 +56,7 @@ struct KParams {
     const T* amp;              // [B] or nullptr
     T* out;                    // rhs / internal force output
     int B, S, G, n_node, off, levels;
+    int lognw;                 // log2(wavefronts per beam); 0 when a wave holds whole beams
     uint32_t flags;
     int imp_slot, imp_dof;
     double duration, t0, dt;
@@ -52,6 +65,7 @@ struct KParams {
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2 };
+constexpr int MAX_LV = 8;
 
 template <typename T>
 struct Lds {
@@ -67,56 +81,94 @@ __host__ __device__ constexpr size_t lds_bytes(int NT) {
     return size_t(14) * size_t(NT) * sizeof(T);
 }
 
+// Where a thread sits: slot j of beam-in-group g, and how to find other slots of its beam.
+struct Topo {
+    int t, lane, j, S, lognw, nwm1, base;
+    bool valid;
+    // thread id (LDS index) of slot jj of this thread's beam
+    __device__ __forceinline__ int thread_of(int jj) const { return base + ((jj & nwm1) << 6) + (jj >> lognw); }
+};
+
+template <typename T>
+__device__ __forceinline__ T shfl_from(T v, int src_lane) {
+    return __shfl(v, src_lane, 64);
+}
+
+// Values of slot j-s ("lo") and j+s ("hi") of a 3-vector r, zero outside the beam.
+// CROSS: through LDS (one barrier); else by lane shuffle inside the wave.
+template <typename T>
+__device__ __forceinline__ void neighbours(const Topo& tp, T* buf, int NT, int s, bool cross, const T r[3], bool want_lo,
+                                           bool want_hi, T rlo[3], T rhi[3]) {
+    const bool lo_ok = tp.j - s >= 0, hi_ok = tp.j + s < tp.S;
+    if (cross) {
+        buf[tp.t] = r[0];
+        buf[NT + tp.t] = r[1];
+        buf[2 * NT + tp.t] = r[2];
+        __syncthreads();
+        const int tl = lo_ok ? tp.thread_of(tp.j - s) : tp.t, th = hi_ok ? tp.thread_of(tp.j + s) : tp.t;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (want_lo) rlo[c] = lo_ok ? buf[c * NT + tl] : T(0);
+            if (want_hi) rhi[c] = hi_ok ? buf[c * NT + th] : T(0);
+        }
+    } else {
+        const int d = s >> tp.lognw;  // lane distance (lognw == 0 when several beams share the wave)
+        const int ll = lo_ok ? tp.lane - d : tp.lane, lh = hi_ok ? tp.lane + d : tp.lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (want_lo) { const T v = shfl_from<T>(r[c], ll); rlo[c] = lo_ok ? v : T(0); }
+            if (want_hi) { const T v = shfl_from<T>(r[c], lh); rhi[c] = hi_ok ? v : T(0); }
+        }
+    }
+}
+
+template <typename T, int LV>
+struct SolveCoef {
+    T lv[LV > 0 ? LV : 1][PCR_LEVEL_VALS];
+    T fin[5];
+};
+
 // One evaluation of a = Minv(-k(q) + f_drag + f_grav + u) for this thread's node.
 // Returns k(q) in `a` (no solve) when KQ_ONLY.
-template <typename T, bool KQ_ONLY>
-__device__ __forceinline__ void stage_accel(const KParams<T>& p, const Lds<T>& lds, const SlotConst<T>& sc, bool active,
-                                            int t, int j, int base, const T q[3], const T v[3], const T uadd[3], T a[3]) {
+template <typename T, int LV, bool KQ_ONLY, bool LEAN>
+__device__ __forceinline__ void stage_accel(const KParams<T>& p, const Lds<T>& lds, const SlotConst<T>& sc,
+                                            const SolveCoef<T, LV>& cf, const Topo& tp, const T q[3], const T v[3],
+                                            const T uadd[3], T a[3]) {
     const int NT = lds.NT;
-    const bool drag_on = (p.flags & 1u) != 0, grav_on = (p.flags & 2u) != 0, corrected = (p.flags & 4u) != 0;
+    // LEAN kernels are only launched for plans without gravity (and calls without a held input)
+    const bool drag_on = (p.flags & 1u) != 0, grav_on = !LEAN && (p.flags & 2u) != 0, corrected = (p.flags & 4u) != 0;
+    const bool cross1 = tp.lognw > 0;  // stride-1 neighbours live in another wave
+    const bool q_in_lds = cross1 || (grav_on && !KQ_ONLY);
 
-    // -- 1. publish q, fetch the left node's q
-    if (active) {
-        lds.q[t] = q[0];
-        lds.q[NT + t] = q[1];
-        lds.q[2 * NT + t] = q[2];
-    }
-    __syncthreads();
-    T ql[3] = {T(0), T(0), T(0)};
-    if (active && j > 0) {
-        ql[0] = lds.q[t - 1];
-        ql[1] = lds.q[NT + t - 1];
-        ql[2] = lds.q[2 * NT + t - 1];
+    // -- 1. the left node's q
+    T ql[3], dummy[3];
+    if (q_in_lds) {
+        neighbours<T>(tp, lds.q, NT, 1, true, q, true, false, ql, dummy);
+    } else {
+        neighbours<T>(tp, lds.q, NT, 1, false, q, true, false, ql, dummy);
     }
     T fl[3], fr[3];
     elem_force<T>(sc.elem, ql, q, corrected, fl, fr);
 
     T gseg[2] = {T(0), T(0)};
-    if (!KQ_ONLY && grav_on && active && sc.half_mass != T(0)) {
+    if (!KQ_ONLY && grav_on && sc.half_mass != T(0)) {
         const int ia = sc.grav.phiA, ib = sc.grav.phiB;
         T phi = T(0);
-        if (ia >= 0) phi = lds.q[(ia & 3) * NT + base + (ia >> 2)];
-        if (ib >= 0) phi = T(0.5) * (phi + lds.q[(ib & 3) * NT + base + (ib >> 2)]);
+        if (ia >= 0) phi = lds.q[(ia & 3) * NT + tp.thread_of(ia >> 2)];
+        if (ib >= 0) phi = T(0.5) * (phi + lds.q[(ib & 3) * NT + tp.thread_of(ib >> 2)]);
         gravity_segment<T>(phi, p.gx, p.gy, sc.half_mass, gseg);
     }
 
-    // -- 2. publish the left-node half of the element force (+ segment gravity)
-    if (active) {
-        lds.f[t] = fl[0];
-        lds.f[NT + t] = fl[1];
-        lds.f[2 * NT + t] = fl[2];
-        if (!KQ_ONLY && grav_on) {
-            lds.g[t] = gseg[0];
-            lds.g[NT + t] = gseg[1];
-        }
+    // -- 2. the right neighbour's left-node half of its element force (+ segment gravity via LDS)
+    T fnext[3];
+    if (!KQ_ONLY && grav_on) {
+        lds.g[tp.t] = gseg[0];
+        lds.g[NT + tp.t] = gseg[1];
     }
-    __syncthreads();
+    neighbours<T>(tp, lds.f, NT, 1, cross1 || (grav_on && !KQ_ONLY), fl, false, true, dummy, fnext);
     T r[3];
-    {
-        const bool has_right = active && (j + 1 < p.S);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) r[c] = fr[c] + (has_right ? lds.f[c * NT + t + 1] : T(0));
-    }
+    for (int c = 0; c < 3; ++c) r[c] = fr[c] + fnext[c];
     if (KQ_ONLY) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a[c] = r[c] * sc.mask[c];
@@ -125,55 +177,26 @@ __device__ __forceinline__ void stage_accel(const KParams<T>& p, const Lds<T>& l
 #pragma unroll
     for (int c = 0; c < 3; ++c) r[c] = uadd[c] - r[c];
     if (drag_on) r[1] += drag_force<T>(sc.drag, v[1]);
-    if (grav_on && active) {
+    if (grav_on) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int sa = sc.grav.segA[c], sb = sc.grav.segB[c];
-            const int off = sc.grav.comp[c] * NT + base;
-            if (sa >= 0) r[c] += lds.g[off + sa];
-            if (sb >= 0) r[c] += lds.g[off + sb];
+            const int go = sc.grav.comp[c] * NT;
+            if (sa >= 0) r[c] += lds.g[go + tp.thread_of(sa)];
+            if (sb >= 0) r[c] += lds.g[go + tp.thread_of(sb)];
         }
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) r[c] *= sc.mask[c];
+    // (no mask multiply: rows/columns of constrained DOFs are zero in every multiplier and in the
+    //  final inverse, so whatever sits in r at a constrained DOF never propagates and a = 0 there)
 
-    // -- 3. Minv by parallel cyclic reduction with precomputed multipliers
-    const T* cf_base = p.pcr_levels + size_t(j) * PCR_LEVEL_VALS;
-    for (int lvl = 0; lvl < p.levels; ++lvl) {
-        const int s = 1 << lvl;
-        T* buf = (lvl & 1) ? lds.r1 : lds.r0;
-        T cf[PCR_LEVEL_VALS];
-        if (active) {
-            const T* src = cf_base + size_t(lvl) * size_t(p.S) * PCR_LEVEL_VALS;
+    // -- 3. Minv by parallel cyclic reduction, multipliers resident in registers
 #pragma unroll
-            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf[k] = src[k];
-            buf[t] = r[0];
-            buf[NT + t] = r[1];
-            buf[2 * NT + t] = r[2];
-        } else {
-#pragma unroll
-            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf[k] = T(0);
-        }
-        __syncthreads();
-        T rlo[3] = {T(0), T(0), T(0)}, rhi[3] = {T(0), T(0), T(0)};
-        if (active && j - s >= 0) {
-            rlo[0] = buf[t - s];
-            rlo[1] = buf[NT + t - s];
-            rlo[2] = buf[2 * NT + t - s];
-        }
-        if (active && j + s < p.S) {
-            rhi[0] = buf[t + s];
-            rhi[1] = buf[NT + t + s];
-            rhi[2] = buf[2 * NT + t + s];
-        }
-        pcr_apply_level<T>(cf, rlo, rhi, r);
+    for (int lvl = 0; lvl < LV; ++lvl) {
+        T rlo[3], rhi[3];
+        neighbours<T>(tp, (lvl & 1) ? lds.r1 : lds.r0, NT, 1 << lvl, lvl < tp.lognw, r, true, true, rlo, rhi);
+        pcr_apply_level<T>(cf.lv[lvl], rlo, rhi, r);
     }
-    {
-        T cf[PCR_FINAL_VALS];
-#pragma unroll
-        for (int k = 0; k < PCR_FINAL_VALS; ++k) cf[k] = active ? p.pcr_final[size_t(j) * PCR_FINAL_VALS + k] : T(0);
-        pcr_apply_final<T>(cf, r, a);
-    }
+    pcr_apply_final<T>(cf.fin, r, a);
 }
 
 template <typename T>
@@ -191,19 +214,50 @@ __device__ __forceinline__ Lds<T> carve_lds(int NT) {
 }
 
 // MODE_STEP: n_steps RK4 steps in place.  MODE_RHS: out = [v ; a].  MODE_KQ: out = k(q).
-template <typename T, int MODE, int MAXT>
-__global__ void __launch_bounds__(MAXT) crb_beam_kernel(const KParams<T> p) {
+template <typename T, int MODE, int LV, int MAXT, int MINW, bool LEAN>
+__global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p) {
     const int NT = blockDim.x;
     const Lds<T> lds = carve_lds<T>(NT);
-    const int t = threadIdx.x;
-    const int g = t / p.S, j = t - g * p.S;
+    Topo tp;
+    tp.t = threadIdx.x;
+    tp.lane = tp.t & 63;
+    tp.S = p.S;
+    tp.lognw = p.lognw;
+    tp.nwm1 = (1 << p.lognw) - 1;
+    int g;
+    if (p.G > 1 || p.lognw == 0) {  // whole beams inside a wave
+        g = tp.t / p.S;
+        tp.j = tp.t - g * p.S;
+        tp.base = g * p.S;
+    } else {  // one beam per workgroup, slots interleaved over the waves
+        g = 0;
+        tp.j = (tp.lane << p.lognw) + (tp.t >> 6);
+        tp.base = 0;
+    }
     const int beam = blockIdx.x * p.G + g;
-    const bool active = (g < p.G) && (beam < p.B);
-    const int base = g * p.S;
+    tp.valid = (g < p.G) && (tp.j < p.S) && (beam < p.B);
+    if (!tp.valid) {
+        // padding thread: an isolated dummy node (no neighbour at any stride, all coefficients 0).
+        // lognw stays the launch value: the barrier / shuffle choice must be workgroup-uniform.
+        tp.j = 0;
+        tp.S = 1;
+        tp.base = tp.t;
+        tp.nwm1 = 0;
+    }
+    const bool valid = tp.valid;
 
     SlotConst<T> sc;
-    if (active) {
-        sc = p.slot[j];
+    SolveCoef<T, LV> cf;
+    if (valid) {
+        sc = p.slot[tp.j];
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+            const T* src = p.pcr_levels + (size_t(l) * size_t(p.S) + size_t(tp.j)) * PCR_LEVEL_VALS;
+#pragma unroll
+            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(tp.j) * PCR_FINAL_VALS + k];
     } else {
         sc.elem.kind = KIND_NONE;
 #pragma unroll
@@ -213,37 +267,39 @@ __global__ void __launch_bounds__(MAXT) crb_beam_kernel(const KParams<T> p) {
         sc.grav.phiA = sc.grav.phiB = -1;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { sc.grav.segA[c] = sc.grav.segB[c] = -1; sc.grav.comp[c] = 0; }
+#pragma unroll
+        for (int l = 0; l < LV; ++l)
+#pragma unroll
+            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
     }
 
     // this thread's node record
-    const size_t node = size_t(j + p.off);
+    const size_t node = size_t(tp.j + p.off);
     const size_t plane = size_t(p.n_node) * 4;
-    const size_t xoff = active ? (size_t(beam) * 2 * plane + node * 4) : 0;
+    const size_t xoff = valid ? (size_t(beam) * 2 * plane + node * 4) : 0;
     T x[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     T uh[3] = {T(0), T(0), T(0)};
-    T amp[3] = {T(0), T(0), T(0)};
-    if (active) {
+    T amp = T(0);
+    if (valid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             x[c] = p.x[xoff + c] * sc.mask[c];
             x[3 + c] = p.x[xoff + plane + c] * sc.mask[c];
         }
-        if (p.u_held) {
+        if (!LEAN && p.u_held) {
             const size_t uoff = size_t(beam) * plane + node * 4;
 #pragma unroll
             for (int c = 0; c < 3; ++c) uh[c] = p.u_held[uoff + c];
         }
-        if (p.amp && j == p.imp_slot) {
-            const T av = p.amp[beam];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) amp[c] = (c == p.imp_dof) ? av : T(0);
-        }
+        if (p.amp && tp.j == p.imp_slot) amp = p.amp[beam];
     }
 
     if (MODE != MODE_STEP) {
         T a[3];
-        stage_accel<T, MODE == MODE_KQ>(p, lds, sc, active, t, j, base, x, x + 3, uh, a);
-        if (active) {
+        stage_accel<T, LV, MODE == MODE_KQ, LEAN>(p, lds, sc, cf, tp, x, x + 3, uh, a);
+        if (valid) {
             if (MODE == MODE_KQ) {
                 const size_t ooff = size_t(beam) * plane + node * 4;
 #pragma unroll
@@ -274,11 +330,11 @@ __global__ void __launch_bounds__(MAXT) crb_beam_kernel(const KParams<T> p) {
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
             const double ts = (s == 0) ? tc : ((s == 3) ? t_full : t_half);
-            const bool on = ts < p.duration;
+            const T av = (ts < p.duration) ? amp : T(0);
             T uadd[3], a[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) uadd[c] = uh[c] + (on ? amp[c] : T(0));
-            stage_accel<T, false>(p, lds, sc, active, t, j, base, xs, xs + 3, uadd, a);
+            for (int c = 0; c < 3; ++c) uadd[c] = (LEAN ? T(0) : uh[c]) + ((c == p.imp_dof) ? av : T(0));
+            stage_accel<T, LV, false, LEAN>(p, lds, sc, cf, tp, xs, xs + 3, uadd, a);
             const T w = (s == 0 || s == 3) ? T(1) : T(2);
             const T cs = (s == 2) ? dt : hdt;
 #pragma unroll
@@ -294,7 +350,7 @@ __global__ void __launch_bounds__(MAXT) crb_beam_kernel(const KParams<T> p) {
         for (int c = 0; c < 6; ++c) x[c] += dt6 * acc[c];
         tc = t_full;
     }
-    if (active) {
+    if (valid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             p.x[xoff + c] = x[c];

@@ -27,7 +27,7 @@ static int fail(int code, const std::string& msg) {
 struct crb_plan {
     int device = -1, dtype = CRB_F64, B = 0;
     int n_elem = 0, n_node = 0, n_free = 0, off = 0, S = 0, G = 1, NT = 64;
-    int levels = 0, levels_full = 0;
+    int levels = 0, levels_full = 0, lognw = 0;
     uint32_t flags = 0;
     double gx = 0, gy = 0;
     std::vector<int32_t> free_index;  // reduced -> full
@@ -153,8 +153,17 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
     p->S = nn - p->off;
     const int S = p->S;
     if (S > 1024) { delete p; return fail(CRB_EUNSUPPORTED, "more than 1024 thread-carried nodes per beam"); }
-    if (S >= 64) { p->G = 1; p->NT = (S + 63) / 64 * 64; }
-    else { p->G = 64 / S; p->NT = 64; }
+    // S >= 64: one beam per workgroup of NW = 2^lognw wavefronts (slots interleaved over the waves);
+    // S < 64: G = 64/S whole beams per single-wave workgroup
+    p->lognw = 0;
+    if (S >= 64) {
+        p->G = 1;
+        while ((64 << p->lognw) < S) ++p->lognw;
+        p->NT = 64 << p->lognw;
+    } else {
+        p->G = 64 / S;
+        p->NT = 64;
+    }
     int lf = 0;
     while ((1 << lf) < S) ++lf;
     p->levels_full = lf;
@@ -271,14 +280,23 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
     int used = lf;
     while (used > 0 && p->h_norms[used - 1] < tol) --used;
     p->levels = used;
+    if (used > MAX_LV) {
+        delete p;
+        return fail(CRB_EUNSUPPORTED, "mass matrix needs more cyclic-reduction levels than the kernels carry in registers");
+    }
     p->h_final.assign(size_t(S) * PCR_FINAL_VALS, 0.0);
     for (int j = 0; j < S; ++j) {
         const NodeBlocks& b = states[used][j];
         double Bi[4];
         inv2(b.B, Bi);
         double* o = &p->h_final[size_t(j) * PCR_FINAL_VALS];
-        o[0] = 1.0 / b.b_ax;
-        for (int k = 0; k < 4; ++k) o[1 + k] = Bi[k];
+        // constrained DOFs: zero row/column in the final inverse, so the kernels need no mask multiply
+        const double mu = slots[j].mask[0], mw = slots[j].mask[1], mp = slots[j].mask[2];
+        o[0] = mu / b.b_ax;
+        o[1] = mw * mw * Bi[0];
+        o[2] = mw * mp * Bi[1];
+        o[3] = mp * mw * Bi[2];
+        o[4] = mp * mp * Bi[3];
         o[5] = 0.0;
     }
 
@@ -391,6 +409,7 @@ KParams<T> base_params(const crb_plan* p) {
     k.n_node = p->n_node;
     k.off = p->off;
     k.levels = p->levels;
+    k.lognw = p->lognw;
     k.flags = p->flags;
     k.imp_slot = -1;
     k.imp_dof = 0;
@@ -400,16 +419,44 @@ KParams<T> base_params(const crb_plan* p) {
     return k;
 }
 
-template <typename T, int MODE>
-int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+template <typename T, int MODE, int LV, bool LEAN>
+int launch_beam_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);
     const size_t smem = lds_bytes<T>(p->NT);
+    // register budget: <=256-thread groups run 2 groups per CU (2 waves/SIMD, 256 VGPRs) so that the
+    // solve multipliers stay in registers; 1024-thread groups get what their size allows
     if (p->NT <= 256)
-        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, 256>), grid, block, smem, st, k);
+        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 256, 2, LEAN>), grid, block, smem, st, k);
+    else if (p->NT <= 512)
+        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 512, 2, LEAN>), grid, block, smem, st, k);
     else
-        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, 1024>), grid, block, smem, st, k);
+        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 1024, 4, LEAN>), grid, block, smem, st, k);
     HIP_TRY(hipGetLastError());
     return CRB_OK;
+}
+
+template <typename T, int MODE, int LV>
+int launch_beam_lv(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    // LEAN: the stepper without gravity tables and without a held input (BASELINE config 3/4)
+    if (MODE == MODE_STEP && !(p->flags & CRB_FORCE_GRAVITY) && !k.u_held)
+        return launch_beam_lean<T, MODE, LV, MODE == MODE_STEP>(p, k, st);
+    return launch_beam_lean<T, MODE, LV, false>(p, k, st);
+}
+
+template <typename T, int MODE>
+int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    switch (p->levels) {
+        case 0: return launch_beam_lv<T, MODE, 0>(p, k, st);
+        case 1: return launch_beam_lv<T, MODE, 1>(p, k, st);
+        case 2: return launch_beam_lv<T, MODE, 2>(p, k, st);
+        case 3: return launch_beam_lv<T, MODE, 3>(p, k, st);
+        case 4: return launch_beam_lv<T, MODE, 4>(p, k, st);
+        case 5: return launch_beam_lv<T, MODE, 5>(p, k, st);
+        case 6: return launch_beam_lv<T, MODE, 6>(p, k, st);
+        case 7: return launch_beam_lv<T, MODE, 7>(p, k, st);
+        case 8: return launch_beam_lv<T, MODE, 8>(p, k, st);
+        default: return fail(CRB_EUNSUPPORTED, "unsupported number of cyclic-reduction levels");
+    }
 }
 
 template <typename T>
