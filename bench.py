@@ -59,7 +59,12 @@ def cpu_baseline(cols, kw, n_elem, target_s=15.0):
     from tests.helpers import oracle_beam
 
     ob = oracle_beam(cols, **kw)
-    cores = os.cpu_count() or 1
+    # host cores this process may use (a 1-GPU box's share is 16 of the host's cores)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("CRB_BENCH_CPU_THREADS", "16"))))
     # calibrate on one beam, then size the sample for ~target_s of wall time on all cores
     t0 = time.perf_counter()
     ob.rk4_impulse(np.zeros(2 * ob.n), 2e-5, 20, 0.1)
@@ -96,6 +101,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from continuum_robot.batched import BeamEnsemble
+    from continuum_robot.distributed import gather_terminal_states, impulse_amplitudes, shard_range
     from continuum_robot.models.force_params import ForceParams
     from tests.helpers import nitinol_columns, oracle_beam, rel_err
 
@@ -111,8 +117,9 @@ def main():
     torch.cuda.synchronize()
     plan_ms = (time.perf_counter() - t_plan) * 1e3
 
-    gidx = rank * B + np.arange(B)
-    amps = torch.as_tensor(0.1 * (1.0 + gidx / B_total), dtype=dtype, device=ens.device)
+    lo, hi = shard_range(B_total, world, rank)
+    assert hi - lo == B
+    amps = torch.as_tensor(impulse_amplitudes(B_total, lo, hi), dtype=dtype, device=ens.device)
     x0 = None
     if cfg["x0"]:
         rng = np.random.default_rng(1234 + rank)
@@ -137,7 +144,6 @@ def main():
     if args.warmup > 0:
         ens.step(args.warmup, dt, impulse_amp=amps)
     reset()
-    gathered = torch.empty((world,) + tuple(ens.state.shape), dtype=dtype, device=ens.device) if world > 1 else None
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -154,8 +160,7 @@ def main():
         e1.record()
         events.append((e0, e1, k))
         done += k
-    if dist:
-        dist.all_gather_into_tensor(gathered, ens.state)  # the one exchange: terminal states
+    gathered = gather_terminal_states(ens.state)  # the one exchange (RCCL all-gather); no-op at N = 1
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -174,7 +179,7 @@ def main():
     # ---- sanity / parity of what was just timed (after the clock stopped)
     state = ens.unpack_state()
     finite = bool(torch.isfinite(state).all())
-    check = {"finite": finite}
+    check = {"finite": finite, "gathered_beams": int(gathered.shape[0])}
     if rank == 0:
         ob = oracle_beam(cols, **okw)
         b = B - 1

@@ -5,3 +5,12 @@ element assembly, force evaluators, mass solve and time step run as HIP kernels 
 libcrbeam.so (see include/crbeam.h).  ``continuum_robot.batched.BeamEnsemble`` is the batched
 entry point the planning/control layers call.
 """
+from continuum_robot.models.dynamic_beam_model import DynamicEulerBernoulliBeam
+from continuum_robot.models.euler_bernoulli_beam import EulerBernoulliBeam
+from continuum_robot.models.abstractions import (
+    IBeam,
+    ISegment,
+    Properties,
+    ElementType,
+    BoundaryConditionType,
+)

@@ -96,6 +96,7 @@ def load():
     L.crb_plan_get_pcr_tables.argtypes = [vp, _dp, _dp, _dp]
     L.crb_plan_get_slot_tables.argtypes = [vp, _dp, _dp, _dp, C.POINTER(C.c_int16), C.POINTER(C.c_int32)]
     L.crb_plan_get_mass.argtypes = [vp, _dp]
+    L.crb_plan_get_stiffness.argtypes = [vp, _dp]
     for name in ("crb_pack_state", "crb_unpack_state", "crb_pack_vec", "crb_unpack_vec", "crb_internal_force"):
         getattr(L, name).argtypes = [vp, vp, vp, vp]
     L.crb_rhs.argtypes = [vp, vp, vp, vp, vp]
@@ -183,6 +184,11 @@ class Plan:
         M = np.empty((self.n_free, self.n_free))
         check(load().crb_plan_get_mass(self.h, M.ctypes.data_as(_dp)))
         return M
+
+    def stiffness(self):
+        K = np.empty((self.n_free, self.n_free))
+        check(load().crb_plan_get_stiffness(self.h, K.ctypes.data_as(_dp)))
+        return K
 
     def pcr_tables(self):
         S, lf = self.n_slots, self.pcr_levels_full

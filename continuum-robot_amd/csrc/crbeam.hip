@@ -32,7 +32,8 @@ struct crb_plan {
     double gx = 0, gy = 0;
     std::vector<int32_t> free_index;  // reduced -> full
     std::vector<int32_t> full2red;    // full -> reduced or -1
-    std::vector<double> h_levels, h_final, h_norms, h_mass;
+    std::vector<double> h_levels, h_final, h_norms, h_mass, h_stiff;
+    int first_nonlinear = -1;
     std::vector<crb::SlotConst<double>> h_slots;
     std::vector<int> h_kinds;
     // device
@@ -250,6 +251,26 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
             }
         }
     }
+    {   // dense reduced stiffness of the linear elements (get_stiffness_matrix); columns = K_e * unit vectors
+        p->h_stiff.assign(size_t(n) * n, 0.0);
+        for (int e = 0; e < ne; ++e) {
+            if (d->nonlinear[e]) { if (p->first_nonlinear < 0) p->first_nonlinear = e; continue; }
+            ElemCoef<double> ec;
+            elem_coef_build<double>(ec, KIND_LINEAR, d->length[e], d->elastic_modulus[e], d->moment_inertia[e],
+                                    d->cross_area[e]);
+            for (int col = 0; col < 6; ++col) {
+                double xe[6] = {0, 0, 0, 0, 0, 0}, fl[3], fr[3];
+                xe[col] = 1.0;
+                elem_force_linear<double>(ec.c, xe, xe + 3, fl, fr);
+                const int rc = p->full2red[3 * e + col];
+                if (rc < 0) continue;
+                for (int row = 0; row < 6; ++row) {
+                    const int rr = p->full2red[3 * e + row];
+                    if (rr >= 0) p->h_stiff[size_t(rr) * n + rc] += row < 3 ? fl[row] : fr[row - 3];
+                }
+            }
+        }
+    }
     std::vector<std::vector<NodeBlocks>> states;
     states.push_back(cur);
     p->h_levels.assign(size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS, 0.0);
@@ -381,6 +402,16 @@ extern "C" int crb_plan_get_slot_tables(const crb_plan* p, double* drag, double*
 extern "C" int crb_plan_get_mass(const crb_plan* p, double* M) {
     if (!p || !M) return fail(CRB_EINVAL, "null argument");
     std::memcpy(M, p->h_mass.data(), p->h_mass.size() * sizeof(double));
+    return CRB_OK;
+}
+
+extern "C" int crb_plan_get_stiffness(const crb_plan* p, double* K) {
+    if (!p || !K) return fail(CRB_EINVAL, "null argument");
+    if (p->first_nonlinear >= 0)
+        return fail(CRB_EINVAL, "Cannot extract stiffness matrix from beam with nonlinear segments. Segment " +
+                                    std::to_string(p->first_nonlinear) +
+                                    " is nonlinear. Stiffness matrix is only valid for purely linear beams.");
+    std::memcpy(K, p->h_stiff.data(), p->h_stiff.size() * sizeof(double));
     return CRB_OK;
 }
 

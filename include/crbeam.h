@@ -124,6 +124,10 @@ int crb_plan_get_slot_tables(const crb_plan* plan, double* drag, double* half_ma
 /* Dense reduced mass matrix as assembled by the plan, [n_free][n_free] host fp64
  * (EulerBernoulliBeam.get_mass_matrix, euler_bernoulli_beam.py:358-362). */
 int crb_plan_get_mass(const crb_plan* plan, double* M);
+/* Dense reduced stiffness matrix of an all-linear beam, [n_free][n_free] host fp64
+ * (EulerBernoulliBeam.get_stiffness_matrix, euler_bernoulli_beam.py:422-511); CRB_EINVAL with the
+ * reference's message when a segment is nonlinear. */
+int crb_plan_get_stiffness(const crb_plan* plan, double* K);
 
 /* reduced [B][2n] <-> device layout [B][2][n_node][4]  (stiffness_with_boundary's
  * scatter/gather, euler_bernoulli_beam.py:280-289, done once at the API edge) */

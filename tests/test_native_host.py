@@ -236,6 +236,11 @@ def test_plan_mass_masks_and_solve_tables(golden, bname, sname):
     M = z[f"{key}/M"]
     assert plan.n_free == M.shape[0]
     assert rel_err(plan.mass(), M) < 1e-15
+    if f"{key}/K" in z.files:
+        assert rel_err(plan.stiffness(), z[f"{key}/K"]) < 1e-15
+    elif bname != "test4_lin":
+        with pytest.raises(native().NativeError, match="Cannot extract stiffness matrix from beam with nonlinear"):
+            plan.stiffness()
     assert np.array_equal(plan.free_index % 3, z[f"{key}/dof_param"])
     assert np.array_equal(plan.free_index // 3, z[f"{key}/dof_node"])
     assert plan.node_offset == (1 if z[f"{key}/node_bc"][0] == 1 else 0)
