@@ -359,6 +359,259 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
     }
 }
 
+// ------------------------------------------------------------------ lean fused stepper
+// crb_step_lean_kernel: the stepper for plans without gravity and calls without a held input
+// (BASELINE configs 3/4), one beam per workgroup of NW = 2^LOGNW waves, everything compile-time:
+//   * exchange rounds merged.  Positions of the NEXT stage are known when a stage starts
+//     (q_next = x_q + c*v_stage), so they ride on this stage's force exchange instead of costing a
+//     round of their own; the force exchange itself is merged with cyclic-reduction level 0: a
+//     thread publishes {q_next, p = u - f_right + drag, f_left} once and rebuilds r of both
+//     neighbours from what it reads (r_{i-1} = p_{i-1} - f_left_i, r_{i+1} = p_{i+1} - f_left_{i+2}).
+//     Rounds per RHS: 1 + (LV-1) instead of 2 + LV; barriers: max(LOGNW,1) [0 for one wave].
+//   * round A moves 16-byte LDS words (record = 10 fp64 / 12 fp32 values per thread, padded so
+//     that ds_read/write_b128 are bank-conflict free); lane +-1 shifts use DPP wave_shr/wave_shl
+//     (no LDS round trip), larger lane shifts ds_bpermute.
+template <typename T>
+struct LeanRec {                    // [qn0 qn1 qn2 - | p0 p1 p2 fl0 | fl1 fl2 (- -)]
+    static constexpr int N = sizeof(T) == 8 ? 10 : 12;
+};
+template <typename T>
+__host__ __device__ constexpr size_t lean_lds_bytes(int NT, int lognw) {
+    // round A records (double-buffered when it is the only barrier round) + SoA buffers of the
+    // cross-wave levels 1..lognw-1
+    return size_t(NT) * sizeof(T) * (size_t(LeanRec<T>::N) * (lognw == 1 ? 2 : 1) + 3 * size_t(lognw > 1 ? lognw - 1 : 0));
+}
+
+__device__ __forceinline__ double dpp_from_lower(double x) {  // value held by lane-1 (0 into lane 0)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_higher(double x) {  // value held by lane+1 (0 into lane 63)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float dpp_from_lower(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_higher(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, false));
+}
+// value of lane-D / lane+D of the same wave
+template <typename T, int D>
+__device__ __forceinline__ T lane_lower(T x, int lane) {
+    if (D == 1) return dpp_from_lower(x);
+    return __shfl(x, lane - D, 64);
+}
+template <typename T, int D>
+__device__ __forceinline__ T lane_higher(T x, int lane) {
+    if (D == 1) return dpp_from_higher(x);
+    return __shfl(x, lane + D, 64);
+}
+
+template <typename T, int LV, int LOGNW>
+__global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KParams<T> p) {
+    static_assert(LV >= 1, "lean stepper needs at least one reduction level");
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
+    T* const ldsA = reinterpret_cast<T*>(crb_smem);
+    T* const ldsB = ldsA + size_t(NT) * RN * (LOGNW == 1 ? 2 : 1);  // [level-1][3][NT]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int S = p.S;
+    const int j = (lane << LOGNW) | wave;
+    const int beam = blockIdx.x;
+    const bool valid = j < S;
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    const bool lo1 = valid && j >= 1, hi1 = valid && j + 1 < S, hi2 = valid && j + 2 < S;
+
+    // ---- per-thread constants
+    ElemCoef<T> ec;
+    T dragc = T(0);
+    SolveCoef<T, LV> cf;
+    if (valid) {
+        const SlotConst<T>& sc = p.slot[j];
+        ec = sc.elem;
+        dragc = (p.flags & 1u) ? sc.drag : T(0);
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+            const T* src = p.pcr_levels + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+#pragma unroll
+            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(j) * PCR_FINAL_VALS + k];
+    } else {
+        ec.kind = KIND_NONE;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ec.c[k] = T(0);
+#pragma unroll
+        for (int l = 0; l < LV; ++l)
+#pragma unroll
+            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
+    }
+    const bool corrected = (p.flags & 4u) != 0;
+
+    // ---- state
+    const size_t node = size_t(valid ? j + p.off : 0);
+    const size_t plane = size_t(p.n_node) * 4;
+    const size_t xoff = size_t(beam) * 2 * plane + node * 4;
+    T xq[3] = {T(0), T(0), T(0)}, xv[3] = {T(0), T(0), T(0)};
+    T amp = T(0);
+    if (valid) {
+        const SlotConst<T>& sc = p.slot[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xq[c] = p.x[xoff + c] * sc.mask[c];
+            xv[c] = p.x[xoff + plane + c] * sc.mask[c];
+        }
+        if (p.amp && j == p.imp_slot) amp = p.amp[beam];
+    }
+
+    // ---- left neighbour's q for the very first stage
+    T qL[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const T v = lane_lower<T, 1>(xq[c], lane); qL[c] = lo1 ? v : T(0); }
+    } else {
+        T* rec = ldsA + size_t(t) * RN;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rec[c] = xq[c];
+        __syncthreads();
+        const T* recl = ldsA + size_t(lo1 ? thread_of(j - 1) : t) * RN;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const T v = recl[c]; qL[c] = lo1 ? v : T(0); }
+        __syncthreads();
+    }
+
+    const T dt = T(p.dt), hdt = T(0.5 * p.dt), dt6 = T(p.dt / 6.0);
+    double tc = p.t0;
+    T accq[3], accv[3], sq[3], sv[3];  // RK4 accumulators and stage state
+    for (int step = 0; step < p.n_steps; ++step) {
+        const double t_half = __dadd_rn(tc, 0.5 * p.dt), t_full = __dadd_rn(tc, p.dt);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { accq[c] = T(0); accv[c] = T(0); sq[c] = xq[c]; sv[c] = xv[c]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double ts = (s == 0) ? tc : ((s == 3) ? t_full : t_half);
+            const T av = (ts < p.duration) ? amp : T(0);
+            const T w = (s == 0 || s == 3) ? T(1) : T(2);
+            const T cs = (s == 2) ? dt : hdt;
+
+            // -- positions of the next stage (or of the next step after stage 3)
+            T qn[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                accq[c] += w * sv[c];
+                qn[c] = (s == 3) ? (xq[c] + dt6 * accq[c]) : (xq[c] + cs * sv[c]);
+            }
+            // -- element force of the element left of this node
+            T fl[3], fr[3];
+            elem_force<T>(ec, qL, sq, corrected, fl, fr);
+            T pp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pp[c] = ((c == p.imp_dof) ? av : T(0)) - fr[c];
+            pp[1] += drag_force<T>(dragc, sv[1]);
+
+            // -- round A: publish {qn, p, fl}; rebuild r of this node and of both stride-1 neighbours
+            T r[3], rlo[3], rhi[3], qLn[3];
+            if (LOGNW == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const T qnl = lane_lower<T, 1>(qn[c], lane), pl = lane_lower<T, 1>(pp[c], lane);
+                    const T pr = lane_higher<T, 1>(pp[c], lane), flr = lane_higher<T, 1>(fl[c], lane);
+                    const T flr2 = lane_higher<T, 2>(fl[c], lane);
+                    qLn[c] = lo1 ? qnl : T(0);
+                    rlo[c] = lo1 ? (pl - fl[c]) : T(0);
+                    r[c] = pp[c] - (hi1 ? flr : T(0));
+                    rhi[c] = hi1 ? (pr - (hi2 ? flr2 : T(0))) : T(0);
+                }
+            } else {
+                T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT) * RN : 0);
+                T* rec = bufA + size_t(t) * RN;
+                rec[0] = qn[0]; rec[1] = qn[1]; rec[2] = qn[2];
+                rec[4] = pp[0]; rec[5] = pp[1]; rec[6] = pp[2];
+                rec[7] = fl[0]; rec[8] = fl[1]; rec[9] = fl[2];
+                __syncthreads();
+                const T* recl = bufA + size_t(lo1 ? thread_of(j - 1) : t) * RN;
+                const T* recr = bufA + size_t(hi1 ? thread_of(j + 1) : t) * RN;
+                const T* recr2 = bufA + size_t(hi2 ? thread_of(j + 2) : t) * RN;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const T qnl = recl[c], pl = recl[4 + c], pr = recr[4 + c], flr = recr[7 + c], flr2 = recr2[7 + c];
+                    qLn[c] = lo1 ? qnl : T(0);
+                    rlo[c] = lo1 ? (pl - fl[c]) : T(0);
+                    r[c] = pp[c] - (hi1 ? flr : T(0));
+                    rhi[c] = hi1 ? (pr - (hi2 ? flr2 : T(0))) : T(0);
+                }
+            }
+            pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+
+            // -- remaining reduction levels
+#pragma unroll
+            for (int l = 1; l < LV; ++l) {
+                const int st = 1 << l;
+                const bool lo_ok = valid && j - st >= 0, hi_ok = valid && j + st < S;
+                if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
+                    T* buf = ldsB + size_t(l - 1) * 3 * NT;
+                    buf[t] = r[0]; buf[NT + t] = r[1]; buf[2 * NT + t] = r[2];
+                    __syncthreads();
+                    const int tl = lo_ok ? thread_of(j - st) : t, th = hi_ok ? thread_of(j + st) : t;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const T a = buf[c * NT + tl], b = buf[c * NT + th];
+                        rlo[c] = lo_ok ? a : T(0);
+                        rhi[c] = hi_ok ? b : T(0);
+                    }
+                } else {
+                    constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        T a, b;
+                        switch (l - LOGNW) {
+                            case 0: a = lane_lower<T, 1>(r[c], lane); b = lane_higher<T, 1>(r[c], lane); break;
+                            case 1: a = lane_lower<T, 2>(r[c], lane); b = lane_higher<T, 2>(r[c], lane); break;
+                            case 2: a = lane_lower<T, 4>(r[c], lane); b = lane_higher<T, 4>(r[c], lane); break;
+                            case 3: a = lane_lower<T, 8>(r[c], lane); b = lane_higher<T, 8>(r[c], lane); break;
+                            case 4: a = lane_lower<T, 16>(r[c], lane); b = lane_higher<T, 16>(r[c], lane); break;
+                            default: a = lane_lower<T, 32>(r[c], lane); b = lane_higher<T, 32>(r[c], lane); break;
+                        }
+                        rlo[c] = lo_ok ? a : T(0);
+                        rhi[c] = hi_ok ? b : T(0);
+                    }
+                }
+                pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
+            }
+            T a[3];
+            pcr_apply_final<T>(cf.fin, r, a);
+
+            // -- RK4 bookkeeping
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                accv[c] += w * a[c];
+                sq[c] = qn[c];
+                sv[c] = (s == 3) ? (xv[c] + dt6 * accv[c]) : (xv[c] + cs * a[c]);
+                qL[c] = qLn[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xq[c] = sq[c]; xv[c] = sv[c]; }
+        tc = t_full;
+    }
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            p.x[xoff + c] = xq[c];
+            p.x[xoff + plane + c] = xv[c];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ layout conversion
 // reduced [B][rows*n_free] <-> device [B][rows][n_node][4]; free_index[r] = 3*node + dof
 template <typename T, bool PACK>

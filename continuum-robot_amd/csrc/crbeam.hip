@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -490,6 +491,37 @@ int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     }
 }
 
+// Fast path of crb_step_rk4: no gravity tables, no held input, one beam per workgroup.
+template <typename T, int LV, int LOGNW>
+int launch_lean_one(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    const dim3 grid(p->B), block(64 << LOGNW);
+    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW>), grid, block, lean_lds_bytes<T>(64 << LOGNW, LOGNW), st, k);
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}
+template <typename T, int LV>
+int launch_lean_lv(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    switch (p->lognw) {
+        case 0: return launch_lean_one<T, LV, 0>(p, k, st);
+        case 1: return launch_lean_one<T, LV, 1>(p, k, st);
+        case 2: return launch_lean_one<T, LV, 2>(p, k, st);
+        default: return launch_lean_one<T, LV, 3>(p, k, st);
+    }
+}
+inline bool lean_eligible(const crb_plan* p, const void* held) {
+    return !(p->flags & CRB_FORCE_GRAVITY) && !held && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
+           p->levels >= 3 && p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr;
+}
+template <typename T>
+int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    switch (p->levels) {
+        case 3: return launch_lean_lv<T, 3>(p, k, st);
+        case 4: return launch_lean_lv<T, 4>(p, k, st);
+        case 5: return launch_lean_lv<T, 5>(p, k, st);
+        default: return launch_lean_lv<T, 6>(p, k, st);
+    }
+}
+
 template <typename T>
 int pack_impl(const crb_plan* p, bool pack, int rows, const void* red_in, void* dev, void* red_out, hipStream_t st) {
     const size_t total = size_t(p->B) * rows * p->n_free;
@@ -607,6 +639,7 @@ extern "C" int crb_step_rk4(const crb_plan* p, void* x, double t0, double dt, in
         k.amp = static_cast<const double*>(amp);
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
         k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+        if (lean_eligible(p, held)) return launch_lean<double>(p, k, st);
         return launch_beam<double, MODE_STEP>(p, k, st);
     }
     KParams<float> k = base_params<float>(p);
@@ -615,6 +648,7 @@ extern "C" int crb_step_rk4(const crb_plan* p, void* x, double t0, double dt, in
     k.amp = static_cast<const float*>(amp);
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
     k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+    if (lean_eligible(p, held)) return launch_lean<float>(p, k, st);
     return launch_beam<float, MODE_STEP>(p, k, st);
 }
 
