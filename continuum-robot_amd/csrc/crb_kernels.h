@@ -373,13 +373,15 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
 //     (no LDS round trip), larger lane shifts ds_bpermute.
 template <typename T>
 struct LeanRec {                    // [qn0 qn1 qn2 - | p0 p1 p2 fl0 | fl1 fl2 (- -)]
-    static constexpr int N = sizeof(T) == 8 ? 10 : 12;
+    static constexpr int N = sizeof(T) == 8 ? 10 : 12;   // 80 B / 48 B: conflict-free 16-byte accesses
+    static constexpr int V = 16 / sizeof(T);              // values per 16-byte LDS word
 };
 template <typename T>
 __host__ __device__ constexpr size_t lean_lds_bytes(int NT, int lognw) {
-    // round A records (double-buffered when it is the only barrier round) + SoA buffers of the
-    // cross-wave levels 1..lognw-1
-    return size_t(NT) * sizeof(T) * (size_t(LeanRec<T>::N) * (lognw == 1 ? 2 : 1) + 3 * size_t(lognw > 1 ? lognw - 1 : 0));
+    // round A records (+1 all-zero "no neighbour" record; double-buffered when round A is the only
+    // barrier round) + SoA buffers (+1 zero column) of the cross-wave levels 1..lognw-1
+    return sizeof(T) * (size_t(NT + 1) * LeanRec<T>::N * (lognw == 1 ? 2 : 1) +
+                        3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
 }
 
 __device__ __forceinline__ double dpp_from_lower(double x) {  // value held by lane-1 (0 into lane 0)
@@ -400,25 +402,57 @@ __device__ __forceinline__ float dpp_from_lower(float x) {
 __device__ __forceinline__ float dpp_from_higher(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, false));
 }
-// value of lane-D / lane+D of the same wave
+// Value of lane-D / lane+D of the same wave.  D <= DPP_MAX: chained DPP wave shifts (VALU, no
+// LDS round trip; lanes shifted in from outside the wave read 0).  Larger D: ds_bpermute; a lane
+// index outside the wave wraps to some lane of the SAME beam -- callers only ever multiply such
+// a value by a multiplier that is exactly 0 (no neighbour at that stride).
+#ifndef CRB_DPP_MAX
+#define CRB_DPP_MAX 2
+#endif
 template <typename T, int D>
 __device__ __forceinline__ T lane_lower(T x, int lane) {
-    if (D == 1) return dpp_from_lower(x);
+    if (D <= CRB_DPP_MAX) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) x = dpp_from_lower(x);
+        return x;
+    }
     return __shfl(x, lane - D, 64);
 }
 template <typename T, int D>
 __device__ __forceinline__ T lane_higher(T x, int lane) {
-    if (D == 1) return dpp_from_higher(x);
+    if (D <= CRB_DPP_MAX) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) x = dpp_from_higher(x);
+        return x;
+    }
     return __shfl(x, lane + D, 64);
+}
+
+// 16-byte LDS access of the V values starting at element index I (I % V == 0) of a record
+template <typename T>
+struct Vec16 {
+    typedef T type __attribute__((ext_vector_type(16 / sizeof(T))));
+};
+template <typename T, int FIRST, int LAST>
+__device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
+    constexpr int V = LeanRec<T>::V;
+    typedef typename Vec16<T>::type vec;
+#pragma unroll
+    for (int w = FIRST / V; w <= LAST / V; ++w) {
+        const vec v = *reinterpret_cast<const vec*>(rec + w * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) out[w * V + k] = v[k];
+    }
 }
 
 template <typename T, int LV, int LOGNW>
 __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
-    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N;
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N, RV = LeanRec<T>::V;
+    constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const ldsA = reinterpret_cast<T*>(crb_smem);
-    T* const ldsB = ldsA + size_t(NT) * RN * (LOGNW == 1 ? 2 : 1);  // [level-1][3][NT]
+    T* const ldsB = ldsA + size_t(NT + 1) * RN * (LOGNW == 1 ? 2 : 1);  // [level-1][3][NT+1]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int S = p.S;
@@ -426,7 +460,22 @@ __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KPa
     const int beam = blockIdx.x;
     const bool valid = j < S;
     auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
-    const bool lo1 = valid && j >= 1, hi1 = valid && j + 1 < S, hi2 = valid && j + 2 < S;
+    // LDS positions of the stride-1 / stride-2 neighbours (NULLT outside the beam)
+    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+
+    if (LOGNW > 0 && t == 0) {  // zero the "no neighbour" slots once
+#pragma unroll
+        for (int k = 0; k < RN; ++k) {
+            ldsA[size_t(NULLT) * RN + k] = T(0);
+            if (LOGNW == 1) ldsA[size_t(NT + 1) * RN + size_t(NULLT) * RN + k] = T(0);
+        }
+#pragma unroll
+        for (int l = 1; l < LOGNW; ++l)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ldsB[(size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
+    }
 
     // ---- per-thread constants
     ElemCoef<T> ec;
@@ -477,15 +526,15 @@ __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KPa
     T qL[3];
     if (LOGNW == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const T v = lane_lower<T, 1>(xq[c], lane); qL[c] = lo1 ? v : T(0); }
+        for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(xq[c], lane);  // lane 0 reads 0 = clamped / absent root
     } else {
         T* rec = ldsA + size_t(t) * RN;
 #pragma unroll
         for (int c = 0; c < 3; ++c) rec[c] = xq[c];
         __syncthreads();
-        const T* recl = ldsA + size_t(lo1 ? thread_of(j - 1) : t) * RN;
+        const T* recl = ldsA + size_t(t_l1) * RN;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { const T v = recl[c]; qL[c] = lo1 ? v : T(0); }
+        for (int c = 0; c < 3; ++c) qL[c] = recl[c];
         __syncthreads();
     }
 
@@ -518,71 +567,76 @@ __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KPa
             for (int c = 0; c < 3; ++c) pp[c] = ((c == p.imp_dof) ? av : T(0)) - fr[c];
             pp[1] += drag_force<T>(dragc, sv[1]);
 
-            // -- round A: publish {qn, p, fl}; rebuild r of this node and of both stride-1 neighbours
-            T r[3], rlo[3], rhi[3], qLn[3];
+            // -- round A: publish {qn, p, fl}; rebuild r of this node and of both stride-1 neighbours.
+            // Outside the beam a neighbour reads as zeros (DPP edge / all-zero LDS record).
+            T r[3], rlo[3], rhi[3];
             if (LOGNW == 0) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const T qnl = lane_lower<T, 1>(qn[c], lane), pl = lane_lower<T, 1>(pp[c], lane);
-                    const T pr = lane_higher<T, 1>(pp[c], lane), flr = lane_higher<T, 1>(fl[c], lane);
-                    const T flr2 = lane_higher<T, 2>(fl[c], lane);
-                    qLn[c] = lo1 ? qnl : T(0);
-                    rlo[c] = lo1 ? (pl - fl[c]) : T(0);
-                    r[c] = pp[c] - (hi1 ? flr : T(0));
-                    rhi[c] = hi1 ? (pr - (hi2 ? flr2 : T(0))) : T(0);
+                    // (shuffles stay outside any condition: every lane must take part.  Lanes past
+                    //  the last slot are padding threads whose p and fl are 0, wave edges shift in 0.)
+                    qL[c] = lane_lower<T, 1>(qn[c], lane);
+                    rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+                    r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+                    rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
                 }
             } else {
-                T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT) * RN : 0);
-                T* rec = bufA + size_t(t) * RN;
-                rec[0] = qn[0]; rec[1] = qn[1]; rec[2] = qn[2];
-                rec[4] = pp[0]; rec[5] = pp[1]; rec[6] = pp[2];
-                rec[7] = fl[0]; rec[8] = fl[1]; rec[9] = fl[2];
+                T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT + 1) * RN : 0);
+                typedef typename Vec16<T>::type vec;
+                T out[RN];
+                out[0] = qn[0]; out[1] = qn[1]; out[2] = qn[2]; out[3] = T(0);
+                out[4] = pp[0]; out[5] = pp[1]; out[6] = pp[2];
+                out[7] = fl[0]; out[8] = fl[1]; out[9] = fl[2];
+#pragma unroll
+                for (int k = 10; k < RN; ++k) out[k] = T(0);
+                vec* rec = reinterpret_cast<vec*>(bufA + size_t(t) * RN);
+#pragma unroll
+                for (int wv = 0; wv < RN / RV; ++wv) {
+                    vec v;
+#pragma unroll
+                    for (int k = 0; k < RV; ++k) v[k] = out[wv * RV + k];
+                    rec[wv] = v;
+                }
                 __syncthreads();
-                const T* recl = bufA + size_t(lo1 ? thread_of(j - 1) : t) * RN;
-                const T* recr = bufA + size_t(hi1 ? thread_of(j + 1) : t) * RN;
-                const T* recr2 = bufA + size_t(hi2 ? thread_of(j + 2) : t) * RN;
+                T L[RN], R1[RN], R2[RN];
+                rec_load<T, 0, 6>(bufA + size_t(t_l1) * RN, L);
+                rec_load<T, 4, 9>(bufA + size_t(t_r1) * RN, R1);
+                rec_load<T, 7, 9>(bufA + size_t(t_r2) * RN, R2);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const T qnl = recl[c], pl = recl[4 + c], pr = recr[4 + c], flr = recr[7 + c], flr2 = recr2[7 + c];
-                    qLn[c] = lo1 ? qnl : T(0);
-                    rlo[c] = lo1 ? (pl - fl[c]) : T(0);
-                    r[c] = pp[c] - (hi1 ? flr : T(0));
-                    rhi[c] = hi1 ? (pr - (hi2 ? flr2 : T(0))) : T(0);
+                    qL[c] = L[c];
+                    rlo[c] = L[4 + c] - fl[c];
+                    r[c] = pp[c] - R1[7 + c];
+                    rhi[c] = R1[4 + c] - R2[7 + c];
                 }
             }
             pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
 
-            // -- remaining reduction levels
+            // -- remaining reduction levels (a missing neighbour contributes through a multiplier
+            //    that is exactly 0, so whatever finite value the shuffle returns there is harmless)
 #pragma unroll
             for (int l = 1; l < LV; ++l) {
-                const int st = 1 << l;
-                const bool lo_ok = valid && j - st >= 0, hi_ok = valid && j + st < S;
+                constexpr int dummy = 0; (void)dummy;
                 if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
-                    T* buf = ldsB + size_t(l - 1) * 3 * NT;
-                    buf[t] = r[0]; buf[NT + t] = r[1]; buf[2 * NT + t] = r[2];
+                    const int st = 1 << l;
+                    T* buf = ldsB + size_t(l - 1) * 3 * (NT + 1);
+                    buf[t] = r[0]; buf[(NT + 1) + t] = r[1]; buf[2 * (NT + 1) + t] = r[2];
                     __syncthreads();
-                    const int tl = lo_ok ? thread_of(j - st) : t, th = hi_ok ? thread_of(j + st) : t;
+                    const int tl = (valid && j - st >= 0) ? thread_of(j - st) : NULLT;
+                    const int th = (valid && j + st < S) ? thread_of(j + st) : NULLT;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const T a = buf[c * NT + tl], b = buf[c * NT + th];
-                        rlo[c] = lo_ok ? a : T(0);
-                        rhi[c] = hi_ok ? b : T(0);
-                    }
+                    for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
                 } else {
-                    constexpr int dummy = 0; (void)dummy;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        T a, b;
                         switch (l - LOGNW) {
-                            case 0: a = lane_lower<T, 1>(r[c], lane); b = lane_higher<T, 1>(r[c], lane); break;
-                            case 1: a = lane_lower<T, 2>(r[c], lane); b = lane_higher<T, 2>(r[c], lane); break;
-                            case 2: a = lane_lower<T, 4>(r[c], lane); b = lane_higher<T, 4>(r[c], lane); break;
-                            case 3: a = lane_lower<T, 8>(r[c], lane); b = lane_higher<T, 8>(r[c], lane); break;
-                            case 4: a = lane_lower<T, 16>(r[c], lane); b = lane_higher<T, 16>(r[c], lane); break;
-                            default: a = lane_lower<T, 32>(r[c], lane); b = lane_higher<T, 32>(r[c], lane); break;
+                            case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
+                            case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
+                            case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
+                            case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
+                            case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
+                            default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
                         }
-                        rlo[c] = lo_ok ? a : T(0);
-                        rhi[c] = hi_ok ? b : T(0);
                     }
                 }
                 pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
@@ -596,7 +650,6 @@ __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KPa
                 accv[c] += w * a[c];
                 sq[c] = qn[c];
                 sv[c] = (s == 3) ? (xv[c] + dt6 * accv[c]) : (xv[c] + cs * a[c]);
-                qL[c] = qLn[c];
             }
         }
 #pragma unroll
