@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libcrbeam.so")
+# CRB_LIB_PATH: point at another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("CRB_LIB_PATH") or os.path.join(_HERE, "_lib", "libcrbeam.so")
 
 CRB_OK, CRB_EINVAL, CRB_EHIP, CRB_ENODEV, CRB_EUNSUPPORTED = 0, -1, -2, -3, -4
 CRB_F64, CRB_F32 = 0, 1
