@@ -208,7 +208,8 @@ def main():
                        "plan_ms": plan_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "crb_beam_kernel<MODE_STEP>", "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel": ("crb_step_lean_kernel" if not cfg["gravity"] else "crb_beam_kernel<MODE_STEP>"),
+                         "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "valu_fp64_frac_estimate": (FLOP_PER_ELEM_STEP[cfg["kind"]] * B * ne
                                                      * min(per_launch, args.steps) / avg_launch_s / 1e12)
