@@ -66,32 +66,134 @@ SlotConst<T> convert_slot(const SlotConst<double>& s, int kind, double L, double
     return o;
 }
 
-template <typename T>
-int upload_tables(crb_plan* p, const std::vector<SlotConst<double>>& slots, const std::vector<int>& kinds,
-                  const crb_beam_desc* d) {
-    const int S = p->S;
-    std::vector<SlotConst<T>> hs(S);
-    for (int j = 0; j < S; ++j) {
-        const int e = j + p->off - 1;
-        if (e >= 0)
-            hs[j] = convert_slot<T>(slots[j], kinds[j], d->length[e], d->elastic_modulus[e], d->moment_inertia[e],
-                                    d->cross_area[e]);
-        else
-            hs[j] = convert_slot<T>(slots[j], KIND_NONE, 1, 1, 1, 1);
+// ---- device-side assembly (crb_assemble_kernel) -------------------------------------------------
+template <typename X>
+struct DevBuf {
+    X* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(X)) == hipSuccess ? 0 : -1; }
+    int upload(const X* h, size_t n) {
+        if (alloc(n)) return -1;
+        return (!n || hipMemcpy(p, h, n * sizeof(X), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
     }
-    std::vector<T> lv(size_t(p->levels > 0 ? p->levels : 1) * S * PCR_LEVEL_VALS, T(0));
-    for (size_t i = 0; i < size_t(p->levels) * S * PCR_LEVEL_VALS; ++i) lv[i] = T(p->h_levels[i]);
+};
+
+void mass_from_blocks(crb_plan* p, const std::vector<NodeBlocks>& blk) {
+    const int n = p->n_free, S = p->S;
+    p->h_mass.assign(size_t(n) * n, 0.0);
+    auto put = [&](int fr, int fc, double v) {
+        const int r = p->full2red[fr], c = p->full2red[fc];
+        if (r >= 0 && c >= 0) p->h_mass[size_t(r) * n + c] += v;
+    };
+    for (int j = 0; j < S; ++j) {
+        const int f0 = 3 * (j + p->off);
+        const NodeBlocks& b = blk[j];
+        put(f0, f0, b.b_ax);
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 2; ++c) put(f0 + 1 + r, f0 + 1 + c, b.B[2 * r + c]);
+        if (j + 1 < S) {
+            put(f0, f0 + 3, b.c_ax);
+            put(f0 + 3, f0, b.c_ax);
+            for (int r = 0; r < 2; ++r)
+                for (int c = 0; c < 2; ++c) {
+                    put(f0 + 1 + r, f0 + 4 + c, b.C[2 * r + c]);
+                    put(f0 + 4 + c, f0 + 1 + r, b.C[2 * r + c]);
+                }
+        }
+    }
+}
+
+int pick_levels(crb_plan* p) {
+    // a level whose multipliers are below the unit roundoff of the plan dtype cannot change a
+    // result by more than half an ulp: the reduction stops there (exact to rounding)
+    const double tol = (p->dtype == CRB_F64) ? std::ldexp(1.0, -53) : std::ldexp(1.0, -24);
+    int used = p->levels_full;
+    while (used > 0 && p->h_norms[used - 1] < tol) --used;
+    p->levels = used;
+    return used;
+}
+
+// Runs crb_assemble_kernel on the plan's device and fills both the device tables the steppers
+// load and the host copies the crb_plan_get_* inspectors return.
+template <typename T>
+int device_assemble(crb_plan* p, const crb_beam_desc* d, const std::vector<SlotConst<double>>& slots,
+                    const std::vector<uint8_t>& free_dof) {
+    const int S = p->S, ne = p->n_elem, lf = p->levels_full;
+    DevBuf<double> dL, dE, dI, dRho, dA, dWet, dCd, dFinAll, dNorms, dBlocks, dLv64;
+    DevBuf<uint8_t> dNl, dFree;
+    DevBuf<GravTab> dGrav;
+    std::vector<GravTab> grav(S);
+    for (int j = 0; j < S; ++j) grav[j] = slots[j].grav;
+    const bool drag = d->flags & CRB_FORCE_DRAG;
+    if (dL.upload(d->length, ne) || dE.upload(d->elastic_modulus, ne) || dI.upload(d->moment_inertia, ne) ||
+        dRho.upload(d->density, ne) || dA.upload(d->cross_area, ne) || dNl.upload(d->nonlinear, ne) ||
+        dFree.upload(free_dof.data(), free_dof.size()) || dGrav.upload(grav.data(), S) ||
+        (drag && (dWet.upload(d->wetted_area, ne) || dCd.upload(d->drag_coef, ne))) ||
+        dFinAll.alloc(size_t(lf + 1) * S * PCR_FINAL_VALS) || dNorms.alloc(lf) || dBlocks.alloc(size_t(S) * 15) ||
+        dLv64.alloc(size_t(lf) * S * PCR_LEVEL_VALS))
+        return fail(CRB_EHIP, "crb_plan_create: device allocation/upload failed");
+    HIP_TRY(hipMalloc(&p->d_slot, size_t(S) * sizeof(SlotConst<T>)));
+    HIP_TRY(hipMalloc(&p->d_levels, size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
+    HIP_TRY(hipMalloc(&p->d_final, size_t(S) * PCR_FINAL_VALS * sizeof(T)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), p->free_index.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_free_index, p->free_index.data(), p->free_index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dNorms.p, 0, size_t(lf ? lf : 1) * sizeof(double)));
+
+    AsmParams a;
+    std::memset(&a, 0, sizeof(a));
+    a.L = dL.p; a.E = dE.p; a.I = dI.p; a.rho = dRho.p; a.A = dA.p;
+    a.nonlinear = dNl.p; a.free_dof = dFree.p; a.wet = dWet.p; a.cd = dCd.p; a.grav = dGrav.p;
+    a.fluid_density = d->fluid_density; a.flags = d->flags;
+    a.n_elem = ne; a.n_node = p->n_node; a.off = p->off; a.S = S; a.levels_full = lf;
+    a.slot_out = p->d_slot; a.lv64 = dLv64.p; a.lvT = p->d_levels; a.fin64_all = dFinAll.p; a.norms = dNorms.p;
+    a.blocks0 = dBlocks.p;
+    const int nta = (S + 63) / 64 * 64;
+    const size_t smem = size_t(S) * sizeof(NodeBlocks);
+    if (smem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&crb_assemble_kernel<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
+    hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(1), dim3(nta), smem, nullptr, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+
+    // ---- read back: inspection copies + the level count decision
+    p->h_levels.assign(size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS, 0.0);
+    p->h_norms.assign(size_t(lf > 0 ? lf : 1), 0.0);
+    if (lf > 0) {
+        HIP_TRY(hipMemcpy(p->h_levels.data(), dLv64.p, size_t(lf) * S * PCR_LEVEL_VALS * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(p->h_norms.data(), dNorms.p, size_t(lf) * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    const int used = pick_levels(p);
+    if (used > MAX_LV)
+        return fail(CRB_EUNSUPPORTED, "mass matrix needs more cyclic-reduction levels than the kernels carry in registers");
+    p->h_final.assign(size_t(S) * PCR_FINAL_VALS, 0.0);
+    HIP_TRY(hipMemcpy(p->h_final.data(), dFinAll.p + size_t(used) * S * PCR_FINAL_VALS,
+                      size_t(S) * PCR_FINAL_VALS * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<T> fin(size_t(S) * PCR_FINAL_VALS);
     for (size_t i = 0; i < fin.size(); ++i) fin[i] = T(p->h_final[i]);
-    HIP_TRY(hipMalloc(&p->d_slot, hs.size() * sizeof(SlotConst<T>)));
-    HIP_TRY(hipMalloc(&p->d_levels, lv.size() * sizeof(T)));
-    HIP_TRY(hipMalloc(&p->d_final, fin.size() * sizeof(T)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), p->free_index.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(p->d_slot, hs.data(), hs.size() * sizeof(SlotConst<T>), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p->d_levels, lv.data(), lv.size() * sizeof(T), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->d_final, fin.data(), fin.size() * sizeof(T), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(p->d_free_index, p->free_index.data(), p->free_index.size() * sizeof(int32_t),
-                      hipMemcpyHostToDevice));
+    std::vector<double> b0(size_t(S) * 15);
+    HIP_TRY(hipMemcpy(b0.data(), dBlocks.p, b0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<NodeBlocks> blk(S);
+    for (int j = 0; j < S; ++j) {
+        const double* b = &b0[size_t(j) * 15];
+        blk[j].a_ax = b[0]; blk[j].b_ax = b[1]; blk[j].c_ax = b[2];
+        for (int k = 0; k < 4; ++k) { blk[j].A[k] = b[3 + k]; blk[j].B[k] = b[7 + k]; blk[j].C[k] = b[11 + k]; }
+    }
+    mass_from_blocks(p, blk);
+    std::vector<SlotConst<T>> hs(S);
+    HIP_TRY(hipMemcpy(hs.data(), p->d_slot, size_t(S) * sizeof(SlotConst<T>), hipMemcpyDeviceToHost));
+    p->h_slots.assign(S, SlotConst<double>());
+    p->h_kinds.assign(S, KIND_NONE);
+    for (int j = 0; j < S; ++j) {
+        SlotConst<double>& o = p->h_slots[j];
+        std::memset(&o, 0, sizeof(o));
+        o.drag = double(hs[j].drag);
+        o.half_mass = double(hs[j].half_mass);
+        for (int c = 0; c < 3; ++c) o.mask[c] = double(hs[j].mask[c]);
+        o.grav = hs[j].grav;
+        p->h_kinds[j] = hs[j].elem.kind;
+    }
     return CRB_OK;
 }
 
@@ -214,44 +316,6 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
     p->h_slots = slots;
     p->h_kinds = kinds;
 
-    // ---- mass matrix in node-block form + cyclic-reduction factorisation (all fp64)
-    std::vector<NodeBlocks> cur(S), nxt(S);
-    auto fm = [&](int node, int c) { return node >= 0 && node < nn && free_dof[3 * node + c] != 0; };
-    for (int j = 0; j < S; ++j) {
-        NodeBlocks nb;
-        std::memset(&nb, 0, sizeof(nb));
-        const int node = j + p->off;
-        const int el = node - 1, er = node;
-        if (el >= 0) mass_add_as_left_elem(nb, d->length[el], d->density[el] * d->cross_area[el], j >= 1);
-        if (er < ne) mass_add_as_right_elem(nb, d->length[er], d->density[er] * d->cross_area[er]);
-        const bool hl = j >= 1, hr = j + 1 < S;
-        mass_apply_masks(nb, fm(node, 0), fm(node, 1), fm(node, 2), hl && fm(node - 1, 0), hl && fm(node - 1, 1),
-                         hl && fm(node - 1, 2), hr && fm(node + 1, 0), hr && fm(node + 1, 1), hr && fm(node + 1, 2));
-        cur[j] = nb;
-    }
-    {   // dense reduced mass for inspection (get_mass_matrix)
-        p->h_mass.assign(size_t(n) * n, 0.0);
-        auto put = [&](int fr, int fc, double v) {
-            const int r = p->full2red[fr], c = p->full2red[fc];
-            if (r >= 0 && c >= 0) p->h_mass[size_t(r) * n + c] += v;
-        };
-        for (int j = 0; j < S; ++j) {
-            const int f0 = 3 * (j + p->off);
-            const NodeBlocks& b = cur[j];
-            put(f0, f0, b.b_ax);
-            for (int r = 0; r < 2; ++r)
-                for (int c = 0; c < 2; ++c) put(f0 + 1 + r, f0 + 1 + c, b.B[2 * r + c]);
-            if (j + 1 < S) {
-                put(f0, f0 + 3, b.c_ax);
-                put(f0 + 3, f0, b.c_ax);
-                for (int r = 0; r < 2; ++r)
-                    for (int c = 0; c < 2; ++c) {
-                        put(f0 + 1 + r, f0 + 4 + c, b.C[2 * r + c]);
-                        put(f0 + 4 + c, f0 + 1 + r, b.C[2 * r + c]);
-                    }
-            }
-        }
-    }
     {   // dense reduced stiffness of the linear elements (get_stiffness_matrix); columns = K_e * unit vectors
         p->h_stiff.assign(size_t(n) * n, 0.0);
         for (int e = 0; e < ne; ++e) {
@@ -272,6 +336,24 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
             }
         }
     }
+    if (device < 0) {
+    // ======== host-only plan (inspection): same arithmetic (crb_math.h) in plain C++ ========
+    // ---- mass matrix in node-block form + cyclic-reduction factorisation (all fp64)
+    std::vector<NodeBlocks> cur(S), nxt(S);
+    auto fm = [&](int node, int c) { return node >= 0 && node < nn && free_dof[3 * node + c] != 0; };
+    for (int j = 0; j < S; ++j) {
+        NodeBlocks nb;
+        std::memset(&nb, 0, sizeof(nb));
+        const int node = j + p->off;
+        const int el = node - 1, er = node;
+        if (el >= 0) mass_add_as_left_elem(nb, d->length[el], d->density[el] * d->cross_area[el], j >= 1);
+        if (er < ne) mass_add_as_right_elem(nb, d->length[er], d->density[er] * d->cross_area[er]);
+        const bool hl = j >= 1, hr = j + 1 < S;
+        mass_apply_masks(nb, fm(node, 0), fm(node, 1), fm(node, 2), hl && fm(node - 1, 0), hl && fm(node - 1, 1),
+                         hl && fm(node - 1, 2), hr && fm(node + 1, 0), hr && fm(node + 1, 1), hr && fm(node + 1, 2));
+        cur[j] = nb;
+    }
+    mass_from_blocks(p, cur);
     std::vector<std::vector<NodeBlocks>> states;
     states.push_back(cur);
     p->h_levels.assign(size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS, 0.0);
@@ -296,12 +378,7 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
         cur.swap(nxt);
         states.push_back(cur);
     }
-    // a level whose multipliers are below the unit roundoff of the plan dtype cannot change a
-    // result by more than half an ulp: the reduction stops there (exact to rounding)
-    const double tol = (dtype == CRB_F64) ? std::ldexp(1.0, -53) : std::ldexp(1.0, -24);
-    int used = lf;
-    while (used > 0 && p->h_norms[used - 1] < tol) --used;
-    p->levels = used;
+    const int used = pick_levels(p);
     if (used > MAX_LV) {
         delete p;
         return fail(CRB_EUNSUPPORTED, "mass matrix needs more cyclic-reduction levels than the kernels carry in registers");
@@ -322,6 +399,7 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
         o[5] = 0.0;
     }
 
+    }
     if (device >= 0) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) {
@@ -330,7 +408,9 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
         }
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete p; return fail(CRB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
-        const int rc = (dtype == CRB_F64) ? upload_tables<double>(p, slots, kinds, d) : upload_tables<float>(p, slots, kinds, d);
+        // ======== device plan: crb_assemble_kernel builds every floating-point table ========
+        const int rc = (dtype == CRB_F64) ? device_assemble<double>(p, d, slots, free_dof)
+                                          : device_assemble<float>(p, d, slots, free_dof);
         if (rc != CRB_OK) { crb_plan_destroy(p); return rc; }
     }
     *out = p;

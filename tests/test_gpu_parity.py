@@ -260,3 +260,39 @@ def test_error_paths():
         ens.step(1, 0.0)
     with pytest.raises(ValueError, match="CSV must contain columns"):
         ensemble({k: v for k, v in cols.items() if k != "density"}, 1)
+
+
+@pytest.mark.parametrize("case", ["test4_lin/fixed0", "mixed5/fixed0_pinned2", "hetero7/pinned0_pinnedN", "hetero7/none",
+                                  "nitinol256", "nitinol300_f32"])
+def test_device_assembly_matches_host_assembly(golden, case):
+    """crb_assemble_kernel (device plans) against the plain-C++ assembly of host-only plans: element
+    packs, masks, drag/segment-mass constants, node-block mass and every cyclic-reduction table."""
+    from continuum_robot import _native as nat
+
+    kw = dict(fluid_density=870.0, enable_fluid=True, enable_gravity=True, gravity=[3.0, -9.81, 0.0])
+    dtype = "f64"
+    if case.startswith("nitinol"):
+        n = int(case[7:10])
+        cols, node_bc = nitinol_columns(n, ["nonlinear" if i % 3 else "linear" for i in range(n)]), None
+        dtype = "f32" if case.endswith("f32") else "f64"
+    else:
+        z = golden["g2_assembly"]
+        bname = case.split("/")[0]
+        cols, node_bc = beam_columns(z, bname), z[f"{case}/node_bc"].astype(np.uint8)
+    dev = nat.Plan(cols, node_bc=node_bc, device=0, dtype=dtype, **kw)
+    host = nat.Plan(cols, node_bc=node_bc, device=-1, dtype=dtype, **kw)
+    for f in ("n_free", "node_offset", "n_slots", "threads", "beams_per_group", "pcr_levels", "pcr_levels_full"):
+        assert getattr(dev, f) == getattr(host, f), f
+    assert rel_err(dev.mass(), host.mass()) < 1e-14
+    (lv_d, fin_d, nrm_d), (lv_h, fin_h, nrm_h) = dev.pcr_tables(), host.pcr_tables()
+    used = host.pcr_levels
+    if used:
+        assert rel_err(lv_d[:used], lv_h[:used]) < 1e-12
+    assert rel_err(fin_d, fin_h) < 1e-12
+    assert np.allclose(nrm_d, nrm_h, rtol=1e-10, atol=0)
+    td, th = dev.slot_tables(), host.slot_tables()
+    tol = 1e-6 if dtype == "f32" else 1e-15
+    for k in ("drag", "half_mass"):
+        assert np.allclose(td[k], th[k], rtol=tol, atol=0), k
+    assert np.array_equal(td["mask"], th["mask"]) and np.array_equal(td["grav"], th["grav"])
+    assert np.array_equal(td["elem_kind"], th["elem_kind"])
