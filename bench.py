@@ -39,7 +39,24 @@ CONFIGS = {
                     label="4096 beams x 256 elem, nonlinear Euler-Bernoulli + fluid drag, fp64"),
     "config2": dict(beams=1024, elems=64, kind="linear", drag=False, gravity=True, x0=True,
                     label="1024 beams x 64 elem, linear + gravity, fp64"),
+    # LQR rollout ensemble (BASELINE config 5: 2048 beams/GPU): state feedback u = K(0 - x) at every RK4
+    # stage (stage-split path: one GEMM + one stage kernel per stage).  dt = 5e-6: the closed loop has
+    # |lambda|max = 3.2e5 1/s, RK4 is unstable at the open-loop dt = 2e-5.
+    "config5": dict(beams=2048, elems=128, kind="linear", drag=False, gravity=True, x0=True, lqr=True, dt=5e-6,
+                    amp=10.0, label="2048 beams/GPU x 128 elem, linear + gravity + LQR feedback per stage, fp64"),
 }
+
+
+def lqr_gain(ens):
+    """LQR gain of lqr_control.py:46-84 for the ensemble's (linear) beam: Q = diag(100 I, 10 I), R = I."""
+    from continuum_robot.control import LinearQuadraticRegulator
+
+    K, M = ens.plan.stiffness(), ens.plan.mass()
+    n = K.shape[0]
+    Q = np.eye(2 * n)
+    Q[:n, :n] *= 100
+    Q[n:, n:] *= 10
+    return LinearQuadraticRegulator(K, M, Q, np.eye(n)).compute_gain_matrix()
 
 
 def parse():
@@ -119,7 +136,12 @@ def main():
 
     lo, hi = shard_range(B_total, world, rank)
     assert hi - lo == B
-    amps = torch.as_tensor(impulse_amplitudes(B_total, lo, hi), dtype=dtype, device=ens.device)
+    amps = torch.as_tensor(impulse_amplitudes(B_total, lo, hi, cfg.get("amp", 0.1)), dtype=dtype, device=ens.device)
+    gain = None
+    if cfg.get("lqr"):
+        t_gain = time.perf_counter()
+        gain = torch.as_tensor(lqr_gain(ens), dtype=dtype, device=ens.device)
+        print(f"[bench] LQR gain {tuple(gain.shape)} solved in {time.perf_counter() - t_gain:.1f} s", file=sys.stderr)
     x0 = None
     if cfg["x0"]:
         rng = np.random.default_rng(1234 + rank)
@@ -136,13 +158,20 @@ def main():
             ens.state.copy_(x0)
             ens.time = 0.0
 
-    dt = 2e-5
+    dt = cfg.get("dt", 2e-5)
     per_launch = args.launch_steps if args.launch_steps > 0 else args.steps
+
+    def advance(k):
+        if gain is None:
+            ens.step(k, dt, impulse_amp=amps)
+        else:
+            ens.step_feedback(k, dt, gain, impulse_amp=amps)
+
     # ---- warmup (untimed), then restore the initial state so the timed K steps are the
     # parity-checked trajectory (the shipped nonlinear element is only stable to ~1000 steps)
     reset()
     if args.warmup > 0:
-        ens.step(args.warmup, dt, impulse_amp=amps)
+        advance(args.warmup)
     reset()
     torch.cuda.synchronize()
     if dist:
@@ -156,7 +185,7 @@ def main():
         k = min(per_launch, args.steps - done)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ens.step(k, dt, impulse_amp=amps)
+        advance(k)
         e1.record()
         events.append((e0, e1, k))
         done += k
@@ -183,7 +212,11 @@ def main():
     if rank == 0:
         ob = oracle_beam(cols, **okw)
         b = B - 1
-        ref = ob.rk4_impulse(np.zeros(2 * ob.n) if x0 is None else x0n[b], dt, args.steps, float(amps[b].item()))
+        x0b = np.zeros(2 * ob.n) if x0 is None else x0n[b]
+        if gain is None:
+            ref = ob.rk4_impulse(x0b, dt, args.steps, float(amps[b].item()))
+        else:
+            ref = ob.rk4_feedback(x0b, dt, args.steps, gain.cpu().numpy(), amp=float(amps[b].item()))
         check["rel_err_vs_oracle_last_beam"] = rel_err(state[b].double().cpu().numpy(), ref)
         check["tip_w_last_beam"] = float(state[b, ens.n - 2].item())
 
@@ -208,7 +241,8 @@ def main():
                        "plan_ms": plan_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("crb_step_lean_kernel" if not cfg["gravity"] else "crb_beam_kernel<MODE_STEP>"),
+                         "kernel": ("crb_step_lean_kernel" if not cfg["gravity"] else
+                                    ("crb_beam_kernel<MODE_STAGE> + GEMM" if gain is not None else "crb_beam_kernel<MODE_STEP>")),
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "valu_fp64_frac_estimate": (FLOP_PER_ELEM_STEP[cfg["kind"]] * B * ne

@@ -103,6 +103,7 @@ def load():
     L.crb_rhs.argtypes = [vp, vp, vp, vp, vp]
     L.crb_step_rk4.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), _dp, vp]
     L.crb_gather_dof.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.crb_rk4_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.POINTER(InputDesc), vp]
     _lib = L
     return L
 

@@ -54,7 +54,10 @@ struct KParams {
     T* x;                      // [B][2][n_node][4]
     const T* u_held;           // [B][n_node][4] or nullptr
     const T* amp;              // [B] or nullptr
-    T* out;                    // rhs / internal force output
+    T* out;                    // rhs / internal force output; MODE_STAGE: next stage state
+    const T* xs;               // MODE_STAGE: this stage's state (== x at stage 0)
+    T* acc;                    // MODE_STAGE: RK4 accumulator [B][2][n_node][4]
+    int stage;                 // MODE_STAGE: 0..3
     int B, S, G, n_node, off, levels;
     int lognw;                 // log2(wavefronts per beam); 0 when a wave holds whole beams
     uint32_t flags;
@@ -64,7 +67,7 @@ struct KParams {
     T gx, gy;
 };
 
-enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2 };
+enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
 constexpr int MAX_LV = 8;
 
 template <typename T>
@@ -214,6 +217,9 @@ __device__ __forceinline__ Lds<T> carve_lds(int NT) {
 }
 
 // MODE_STEP: n_steps RK4 steps in place.  MODE_RHS: out = [v ; a].  MODE_KQ: out = k(q).
+// MODE_STAGE: ONE RK4 stage of the stage-split stepper (the input force changes per stage, e.g. state
+// feedback u = K(r - x), lqr_control.py:95-111): k = f(t0, xs, u_held + impulse);
+// acc = (stage ? acc : 0) + w k;  stage < 3: out = x + c k;  stage 3: x += dt/6 acc.
 template <typename T, int MODE, int LV, int MAXT, int MINW, bool LEAN>
 __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p) {
     const int NT = blockDim.x;
@@ -296,6 +302,43 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
         if (p.amp && tp.j == p.imp_slot) amp = p.amp[beam];
     }
 
+    if (MODE == MODE_STAGE) {
+        T xs[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, acc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                xs[c] = p.xs[xoff + c] * sc.mask[c];
+                xs[3 + c] = p.xs[xoff + plane + c] * sc.mask[c];
+                if (p.stage > 0) { acc[c] = p.acc[xoff + c]; acc[3 + c] = p.acc[xoff + plane + c]; }
+            }
+        }
+        const T av = (p.t0 < p.duration) ? amp : T(0);
+        T uadd[3], a[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) uadd[c] = uh[c] + ((c == p.imp_dof) ? av : T(0));
+        stage_accel<T, LV, false, LEAN>(p, lds, sc, cf, tp, xs, xs + 3, uadd, a);
+        const T w = (p.stage == 0 || p.stage == 3) ? T(1) : T(2);
+        const T cs = (p.stage == 2) ? T(p.dt) : T(0.5 * p.dt);
+        const T dt6 = T(p.dt / 6.0);
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const T kq = xs[3 + c], kv = a[c];
+                acc[c] += w * kq;
+                acc[3 + c] += w * kv;
+                if (p.stage < 3) {
+                    p.out[xoff + c] = x[c] + cs * kq;
+                    p.out[xoff + plane + c] = x[3 + c] + cs * kv;
+                    p.acc[xoff + c] = acc[c];
+                    p.acc[xoff + plane + c] = acc[3 + c];
+                } else {
+                    p.x[xoff + c] = x[c] + dt6 * acc[c];
+                    p.x[xoff + plane + c] = x[3 + c] + dt6 * acc[3 + c];
+                }
+            }
+        }
+        return;
+    }
     if (MODE != MODE_STEP) {
         T a[3];
         stage_accel<T, LV, MODE == MODE_KQ, LEAN>(p, lds, sc, cf, tp, x, x + 3, uh, a);

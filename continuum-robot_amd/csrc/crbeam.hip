@@ -732,6 +732,41 @@ extern "C" int crb_step_rk4(const crb_plan* p, void* x, double t0, double dt, in
     return launch_beam<float, MODE_STEP>(p, k, st);
 }
 
+extern "C" int crb_rk4_stage(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage,
+                             int stage, double t_stage, double dt, const crb_input_desc* in, void* stream) {
+    if (int rc = need_device(p, "crb_rk4_stage")) return rc;
+    if (!x || !xs || !acc) return fail(CRB_EINVAL, "crb_rk4_stage: null pointer");
+    if (stage < 0 || stage > 3) return fail(CRB_EINVAL, "crb_rk4_stage: stage must be 0..3");
+    if (stage < 3 && (!xs_next || xs_next == xs)) return fail(CRB_EINVAL, "crb_rk4_stage: xs_next must be a distinct buffer");
+    if (!(dt > 0)) return fail(CRB_EINVAL, "crb_rk4_stage: dt must be positive");
+    int imp_slot = -1, imp_dof = 0;
+    double duration = 0.0;
+    const void* amp = nullptr;
+    if (in && in->kind == CRB_INPUT_IMPULSE) {
+        if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp ||
+            p->full2red[3 * in->node + in->dof] < 0)
+            return fail(CRB_EINVAL, "crb_rk4_stage: bad impulse description");
+        imp_slot = in->node - p->off; imp_dof = in->dof; duration = in->duration; amp = in->amp;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->dtype == CRB_F64) {
+        KParams<double> k = base_params<double>(p);
+        k.x = static_cast<double*>(x); k.xs = static_cast<const double*>(xs); k.acc = static_cast<double*>(acc);
+        k.out = static_cast<double*>(xs_next); k.u_held = static_cast<const double*>(u_stage);
+        k.amp = static_cast<const double*>(amp);
+        k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+        k.stage = stage; k.t0 = t_stage; k.dt = dt;
+        return launch_beam<double, MODE_STAGE>(p, k, st);
+    }
+    KParams<float> k = base_params<float>(p);
+    k.x = static_cast<float*>(x); k.xs = static_cast<const float*>(xs); k.acc = static_cast<float*>(acc);
+    k.out = static_cast<float*>(xs_next); k.u_held = static_cast<const float*>(u_stage);
+    k.amp = static_cast<const float*>(amp);
+    k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+    k.stage = stage; k.t0 = t_stage; k.dt = dt;
+    return launch_beam<float, MODE_STAGE>(p, k, st);
+}
+
 extern "C" int crb_gather_dof(const crb_plan* p, const void* x, int plane, int node, int dof, void* out, void* stream) {
     if (int rc = need_device(p, "crb_gather_dof")) return rc;
     if (!x || !out) return fail(CRB_EINVAL, "crb_gather_dof: null pointer");

@@ -152,6 +152,16 @@ int crb_rhs(const crb_plan* plan, const void* x, const void* u, void* xdot, void
 int crb_step_rk4(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const crb_input_desc* input,
                  double* t_end, void* stream);
 
+/* ONE stage of the stage-split RK4 stepper, for inputs that change from stage to stage -- state
+ * feedback u = K(r - x) evaluated inside the RHS as examples/lqr_control.py:95-111 does
+ * (FullStateLinear.compute_input, control/full_state_linear.py:81).  The caller computes this
+ * stage's generalised force u_stage[B][n_node][4] from xs (e.g. one GEMM over the whole ensemble) and
+ * calls:   k = f(t_stage, xs, u_stage + impulse);  acc = (stage ? acc : 0) + w_stage * k;
+ *          stage < 3: xs_next = x + c_stage * k;      stage == 3: x += dt/6 * acc.
+ * Stage 0 passes xs == x.  x, xs, acc, xs_next: device [B][2][n_node][4]; xs_next may not alias xs. */
+int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage,
+                  int stage, double t_stage, double dt, const crb_input_desc* input, void* stream);
+
 /* out[b] = x[b][plane][node][dof]  (e.g. tip displacement = plane 0, node n_elem, dof 1;
  * lqr_control.py:168) */
 int crb_gather_dof(const crb_plan* plan, const void* x, int plane, int node, int dof, void* out, void* stream);

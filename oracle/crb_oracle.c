@@ -22,6 +22,7 @@
  *                            FULL-layout indices; reproduced as shipped)
  *   orc_rhs                  dynamic_beam_model.py:256-272, 294-328, 343-362
  *                            xdot = [v ; Minv(-k(q) + f(x, t=0) + u)]
+ *   orc_rk4_feedback         the closed loop of examples/lqr_control.py:95-111 (u = K(r-x) per stage)
  *   orc_rk4_*                fixed-step classical RK4 over orc_rhs.  The reference has no
  *                            integrator (callers use scipy.solve_ivp); the loop restated here
  *                            is the one in tests/golden/make_golden.py:rk4.
@@ -485,6 +486,44 @@ void orc_rk4_held(const orc_model* m, double* x, double dt, int n_steps, const d
         for (int i = 0; i < N; ++i) x[i] = x[i] + (dt / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
     }
     free(w);
+}
+
+/* Closed-loop RK4 of examples/lqr_control.py:95-111: at every stage the total input is
+ * u = K (r - x_stage) [control/full_state_linear.py:81] plus the tip impulse; K is [n][2n] row-major,
+ * r [2n] or NULL (= 0).  Clock as in orc_rk4_impulse. */
+double orc_rk4_feedback(const orc_model* m, double* x, double t0, double dt, int n_steps, const double* K,
+                        const double* r, double amp, double duration, int idx) {
+    const int n = m->n_red, N = 2 * n;
+    if (idx < 0) idx += n;
+    double* w = (double*)malloc((size_t)(6 * N + n) * sizeof(double));
+    double *k1 = w, *k2 = w + N, *k3 = w + 2 * N, *k4 = w + 3 * N, *xs = w + 4 * N, *u = w + 5 * N;
+    double t = t0;
+#define ORC_FEEDBACK(state, tt)                                               \
+    for (int i = 0; i < n; ++i) {                                             \
+        double s_ = 0.0;                                                      \
+        for (int j = 0; j < N; ++j) s_ += K[(size_t)i * N + j] * ((r ? r[j] : 0.0) - (state)[j]); \
+        u[i] = s_;                                                            \
+    }                                                                         \
+    if ((tt) < duration) u[idx] += amp;
+    for (int s = 0; s < n_steps; ++s) {
+        const double th = t + 0.5 * dt, t1 = t + dt;
+        ORC_FEEDBACK(x, t)
+        orc_rhs(m, x, u, k1);
+        for (int i = 0; i < N; ++i) xs[i] = x[i] + (0.5 * dt) * k1[i];
+        ORC_FEEDBACK(xs, th)
+        orc_rhs(m, xs, u, k2);
+        for (int i = 0; i < N; ++i) xs[i] = x[i] + (0.5 * dt) * k2[i];
+        ORC_FEEDBACK(xs, th)
+        orc_rhs(m, xs, u, k3);
+        for (int i = 0; i < N; ++i) xs[i] = x[i] + dt * k3[i];
+        ORC_FEEDBACK(xs, t1)
+        orc_rhs(m, xs, u, k4);
+        for (int i = 0; i < N; ++i) x[i] = x[i] + (dt / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        t = t + dt;
+    }
+#undef ORC_FEEDBACK
+    free(w);
+    return t;
 }
 
 /* B independent trajectories of one model (the reference runs such ensembles through

@@ -48,6 +48,9 @@ def lib():
                                       C.c_int]
         L.orc_rk4_impulse.restype = C.c_double
         L.orc_rk4_held.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, _dp]
+        L.orc_rk4_feedback.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp, C.c_double, C.c_double,
+                                       C.c_int]
+        L.orc_rk4_feedback.restype = C.c_double
         L.orc_rk4_impulse_batch.argtypes = [C.c_void_p, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int,
                                             C.c_double, C.c_int, C.c_int]
         L.orc_rk4_impulse_batch.restype = C.c_int
@@ -191,6 +194,15 @@ class OracleBeam:
         x = _d(x0).copy()
         uu = _d(u) if u is not None else None
         lib().orc_rk4_held(self.h, _p(x), dt, n_steps, _p(uu) if uu is not None else None)
+        return x
+
+    def rk4_feedback(self, x0, dt, n_steps, gain, reference=None, amp=0.0, duration=0.01, idx=-2, t0=0.0):
+        x = _d(x0).copy()
+        K = _d(gain)
+        assert K.shape == (self.n, 2 * self.n)
+        r = _d(reference) if reference is not None else None
+        lib().orc_rk4_feedback(self.h, _p(x), t0, dt, n_steps, _p(K), _p(r) if r is not None else None, amp, duration,
+                               idx)
         return x
 
     def rk4_impulse_batch(self, X0, dt, n_steps, amps, duration=0.01, idx=-2, t0=0.0, n_threads=0):

@@ -381,8 +381,84 @@ def g5_rollouts():
     np.savez_compressed(os.path.join(HERE, "g5_rollouts.npz"), **out)
 
 
+# --------------------------------------------------------------------------- G6
+def g6_lqr_loop():
+    """Closed-loop rollout of examples/lqr_control.py:87-130 with fixed-step RK4: the controller
+    u = K (r - x) (control/full_state_linear.py:81, r = 0) is evaluated inside the RHS at every stage,
+    plus the tip impulse of lqr_control.py:33-41.  `control` (python-control) is not installed, so the
+    gain comes from scipy's CARE solver on the A/B of linear_quadratic_regulator.py:84-146 built from
+    the reference's own K and M; the gain is stored, so the fixture pins the LOOP, not the solver."""
+    from scipy.linalg import solve_continuous_are
+
+    out = {}
+    # The closed loop has |lambda|max = 3.24e5 1/s (velocity feedback through the tiny rotational
+    # inertias), so explicit RK4 needs dt <= 2.78/|lambda| = 8.6e-6 s; dt = 2e-5 (SURVEY §8(d)) blows up.
+    dt = 5e-6
+    for name, n_seg, steps in (("lqr6", 6, 3000), ("lqr24", 24, 600)):
+        df = nitinol(n_seg, "linear")
+        kw = dict(enable_gravity_effects=True)
+        out.update(fp_arrays(name, kw))
+        path = write_csv(df)
+        try:
+            beam = DynamicEulerBernoulliBeam(path, force_params=ForceParams(**kw))
+        finally:
+            os.unlink(path)
+        out.update(df_arrays(name, beam.params))
+        beam.create_system_func()
+        beam.create_input_func()
+        dyn = beam.get_dynamic_system()
+        Kb, Mb = beam.beam_model.get_stiffness_matrix(), beam.beam_model.get_mass_matrix()
+        n = Kb.shape[0]
+        Minv = np.linalg.inv(Mb)
+        A = np.zeros((2 * n, 2 * n))
+        A[:n, n:] = np.eye(n)
+        A[n:, :n] = -Minv @ Kb
+        Bm = np.zeros((2 * n, n))
+        Bm[n:, :] = Minv
+        Q = np.eye(2 * n)
+        Q[:n, :n] *= 100  # lqr_control.py:61-66
+        Q[n:, n:] *= 10
+        R = np.eye(n)
+        S = solve_continuous_are(A, Bm, Q, R)
+        gain = np.linalg.solve(R, Bm.T @ S)
+        assert np.all(np.real(np.linalg.eigvals(A - Bm @ gain)) < 0)
+        amp = 10.0
+        x = np.zeros(2 * n)
+        ref = np.zeros(2 * n)
+
+        def total_input(t, xx):
+            u = gain @ (ref - xx)
+            if t < 0.01:
+                u[-2] += amp
+            return u
+
+        t = 0.0
+        for _ in range(steps):
+            th, t1 = t + 0.5 * dt, t + dt
+            k1 = dyn(t, x, total_input(t, x))
+            x2 = x + (0.5 * dt) * k1
+            k2 = dyn(th, x2, total_input(th, x2))
+            x3 = x + (0.5 * dt) * k2
+            k3 = dyn(th, x3, total_input(th, x3))
+            x4 = x + dt * k3
+            k4 = dyn(t1, x4, total_input(t1, x4))
+            x = x + (dt / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+            t = t + dt
+        out[f"{name}/gain"] = gain
+        out[f"{name}/K"] = Kb
+        out[f"{name}/M"] = Mb
+        out[f"{name}/amp"] = np.float64(amp)
+        out[f"{name}/dt"] = np.float64(dt)
+        out[f"{name}/steps"] = np.int32(steps)
+        out[f"{name}/x_final"] = x
+        print(f"G6 {name}: tip w @{steps} = {x[n - 2]!r}, max|gain| = {np.abs(gain).max():.3f}")
+    np.savez_compressed(os.path.join(HERE, "g6_lqr_loop.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6"]
+    if "g6" in which:
+        g6_lqr_loop()
     if "g1" in which:
         g1_elements()
     if "g2" in which:

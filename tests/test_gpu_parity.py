@@ -296,3 +296,30 @@ def test_device_assembly_matches_host_assembly(golden, case):
         assert np.allclose(td[k], th[k], rtol=tol, atol=0), k
     assert np.array_equal(td["mask"], th["mask"]) and np.array_equal(td["grav"], th["grav"])
     assert np.array_equal(td["elem_kind"], th["elem_kind"])
+
+
+@pytest.mark.parametrize("name", ["lqr6", "lqr24"])
+def test_lqr_feedback_rollout_matches_reference(golden, name):
+    """Stage-split RK4 with u = K(r - x) per stage (BASELINE config 5's loop) against the reference
+    (tests/golden/make_golden.py:g6_lqr_loop) and, with per-beam amplitudes and references, the oracle."""
+    z = golden["g6_lqr_loop"]
+    cols, kw = beam_columns(z, name), force_kwargs(z, name)
+    gain, dt, steps, amp = z[f"{name}/gain"], float(z[f"{name}/dt"]), int(z[f"{name}/steps"]), float(z[f"{name}/amp"])
+    B = 4
+    ens = ensemble(cols, B, kw)
+    ens.step_feedback(steps, dt, gain, impulse_amp=np.full(B, amp))
+    got = ens.unpack_state().cpu().numpy()
+    assert rel_err(got[0], z[f"{name}/x_final"]) < 1e-8
+    assert np.array_equal(got[0], got[3])
+    # distinct amplitudes + a nonzero reference, shorter horizon, against the oracle
+    ob = oracle_beam(cols, **kw)
+    n = ob.n
+    amps = amp * (1.0 + np.arange(B) / B)
+    ref = np.zeros((B, 2 * n))
+    ref[:, n - 2] = 1e-3 * (1 + np.arange(B))
+    ens = ensemble(cols, B, kw)
+    ens.step_feedback(300, dt, gain, reference=ref, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    for b in range(B):
+        want = ob.rk4_feedback(np.zeros(2 * n), dt, 300, gain, reference=ref[b], amp=amps[b])
+        assert rel_err(got[b], want) < 1e-9

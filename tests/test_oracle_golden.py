@@ -139,3 +139,14 @@ def test_batch_matches_single():
     assert used == 2
     for b in range(5):
         assert np.array_equal(X[b], ob.rk4_impulse(np.zeros(2 * ob.n), 2e-5, 50, amps[b]))
+
+
+@pytest.mark.parametrize("name", ["lqr6", "lqr24"])
+def test_g6_lqr_closed_loop(golden, name):
+    """orc_rk4_feedback against the reference's RHS driven through the loop of examples/lqr_control.py."""
+    z = golden["g6_lqr_loop"]
+    ob = oracle_beam(beam_columns(z, name), **force_kwargs(z, name))
+    assert rel_err(ob.mass(), z[f"{name}/M"]) < 1e-15 and rel_err(ob.stiffness(), z[f"{name}/K"]) < 1e-15
+    x = ob.rk4_feedback(np.zeros(2 * ob.n), float(z[f"{name}/dt"]), int(z[f"{name}/steps"]), z[f"{name}/gain"],
+                        amp=float(z[f"{name}/amp"]))
+    assert rel_err(x, z[f"{name}/x_final"]) < 1e-9
