@@ -59,6 +59,10 @@ class InputDesc(C.Structure):
     ]
 
 
+class RecordDesc(C.Structure):
+    _fields_ = [("plane", C.c_int32), ("node", C.c_int32), ("dof", C.c_int32), ("every", C.c_int32), ("out", C.c_void_p)]
+
+
 class NativeError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"libcrbeam error {code}: {message}")
@@ -102,6 +106,8 @@ def load():
         getattr(L, name).argtypes = [vp, vp, vp, vp]
     L.crb_rhs.argtypes = [vp, vp, vp, vp, vp]
     L.crb_step_rk4.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), _dp, vp]
+    L.crb_step_rk4_rec.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), C.POINTER(RecordDesc), _dp,
+                                   vp]
     L.crb_gather_dof.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.crb_rk4_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.POINTER(InputDesc), vp]
     _lib = L

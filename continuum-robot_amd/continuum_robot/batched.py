@@ -157,13 +157,16 @@ class BeamEnsemble:
         return self.unpack_state(self.rhs_device(x, u))
 
     def step(self, n_steps: int, dt: float, impulse_amp=None, impulse_duration: float = 0.01,
-             impulse_index: int = -2, held_force=None, t0: Optional[float] = None) -> float:
+             impulse_index: int = -2, held_force=None, t0: Optional[float] = None, record=None, record_every: int = 1):
         """Advance the resident state by ``n_steps`` RK4 steps in one kernel launch.
 
         impulse_amp    per-beam amplitudes [B] of the examples' forcing: that value on reduced
                        position index ``impulse_index`` (-2 = tip w, example_utilities.py:147)
                        while t < impulse_duration
         held_force     reduced [B, n] generalised force held constant over the call
+        record         (node, 'u'|'w'|'phi'|'du_dt'|'dw_dt'|'dphi_dt'): sample that DOF on the device after
+                       every ``record_every``-th step (the t_eval output of the reference's solve_ivp
+                       calls); the call then returns (clock, samples[B, n_steps // record_every])
         Returns the clock after the call (accumulated by addition, as the oracle does).
         """
         if t0 is not None:
@@ -186,12 +189,21 @@ class BeamEnsemble:
             desc.f_held = held.data_ptr()
             keep.append(held)
         t_end = C.c_double(0.0)
+        rec, samples = None, None
+        if record is not None:
+            node, param = record
+            vel = param.startswith("d") and param.endswith("_dt")
+            samples = torch.zeros((self.n_beams, int(n_steps) // int(record_every)), dtype=self.dtype, device=self.device)
+            rec = nat.RecordDesc(int(vel), int(node), _PARAM[param[1:-3] if vel else param], int(record_every),
+                                 samples.data_ptr())
+            keep.append(samples)
         with torch.cuda.device(self.device):
-            nat.check(self._lib.crb_step_rk4(self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps),
-                                             C.byref(desc), C.byref(t_end), self._stream()))
+            nat.check(self._lib.crb_step_rk4_rec(self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps),
+                                                 C.byref(desc), C.byref(rec) if rec is not None else None,
+                                                 C.byref(t_end), self._stream()))
         self._keep = keep  # device buffers must outlive the asynchronous launch
         self.time = t_end.value
-        return self.time
+        return (self.time, samples) if record is not None else self.time
 
     def step_feedback(self, n_steps: int, dt: float, gain, reference=None, impulse_amp=None,
                       impulse_duration: float = 0.01, impulse_index: int = -2, t0: Optional[float] = None) -> float:

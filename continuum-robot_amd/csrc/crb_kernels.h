@@ -58,6 +58,9 @@ struct KParams {
     const T* xs;               // MODE_STAGE: this stage's state (== x at stage 0)
     T* acc;                    // MODE_STAGE: RK4 accumulator [B][2][n_node][4]
     int stage;                 // MODE_STAGE: 0..3
+    T* rec_out;                // MODE_STEP: [B][n_rec] strided record of one DOF, or nullptr
+    int rec_slot, rec_comp;    // recording thread (slot) and component 0..5 of {q, v}
+    int rec_every, rec_n;
     int B, S, G, n_node, off, levels;
     int lognw;                 // log2(wavefronts per beam); 0 when a wave holds whole beams
     uint32_t flags;
@@ -392,6 +395,12 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
 #pragma unroll
         for (int c = 0; c < 6; ++c) x[c] += dt6 * acc[c];
         tc = t_full;
+        if (p.rec_out && valid && tp.j == p.rec_slot && (step + 1) % p.rec_every == 0) {
+            T val = x[0];
+#pragma unroll
+            for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? x[c] : val;
+            p.rec_out[size_t(beam) * p.rec_n + (step + 1) / p.rec_every - 1] = val;
+        }
     }
     if (valid) {
 #pragma unroll
@@ -699,6 +708,12 @@ __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KPa
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xq[c] = sq[c]; xv[c] = sv[c]; }
         tc = t_full;
+        if (p.rec_out && valid && j == p.rec_slot && (step + 1) % p.rec_every == 0) {
+            T val = xq[0];
+#pragma unroll
+            for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? (c < 3 ? xq[c] : xv[c - 3]) : val;
+            p.rec_out[size_t(beam) * p.rec_n + (step + 1) / p.rec_every - 1] = val;
+        }
     }
     if (valid) {
 #pragma unroll

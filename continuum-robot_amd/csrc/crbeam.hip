@@ -680,7 +680,23 @@ extern "C" int crb_rhs(const crb_plan* p, const void* x, const void* u, void* xd
 
 extern "C" int crb_step_rk4(const crb_plan* p, void* x, double t0, double dt, int n_steps, const crb_input_desc* in,
                             double* t_end, void* stream) {
+    return crb_step_rk4_rec(p, x, t0, dt, n_steps, in, nullptr, t_end, stream);
+}
+
+extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt, int n_steps, const crb_input_desc* in,
+                                const crb_record_desc* rec, double* t_end, void* stream) {
     if (int rc = need_device(p, "crb_step_rk4")) return rc;
+    int rec_slot = -1, rec_comp = 0, rec_every = 1, rec_n = 0;
+    void* rec_out = nullptr;
+    if (rec) {
+        if (rec->plane < 0 || rec->plane > 1 || rec->node < 0 || rec->node >= p->n_node || rec->dof < 0 || rec->dof > 2 ||
+            rec->every < 1 || !rec->out)
+            return fail(CRB_EINVAL, "crb_step_rk4_rec: bad record description");
+        rec_n = n_steps / rec->every;
+        if (rec->node - p->off >= 0 && rec_n > 0) {  // (the dropped FIXED node 0 records nothing: it is 0 forever)
+            rec_slot = rec->node - p->off; rec_comp = rec->plane * 3 + rec->dof; rec_every = rec->every; rec_out = rec->out;
+        }
+    }
     if (!x) return fail(CRB_EINVAL, "crb_step_rk4: null state");
     if (n_steps < 0) return fail(CRB_EINVAL, "crb_step_rk4: n_steps must be >= 0");
     if (!(dt > 0)) return fail(CRB_EINVAL, "crb_step_rk4: dt must be positive");
@@ -719,6 +735,7 @@ extern "C" int crb_step_rk4(const crb_plan* p, void* x, double t0, double dt, in
         k.amp = static_cast<const double*>(amp);
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
         k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+        k.rec_out = static_cast<double*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
         if (lean_eligible(p, held)) return launch_lean<double>(p, k, st);
         return launch_beam<double, MODE_STEP>(p, k, st);
     }
@@ -728,6 +745,7 @@ extern "C" int crb_step_rk4(const crb_plan* p, void* x, double t0, double dt, in
     k.amp = static_cast<const float*>(amp);
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
     k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+    k.rec_out = static_cast<float*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
     if (lean_eligible(p, held)) return launch_lean<float>(p, k, st);
     return launch_beam<float, MODE_STEP>(p, k, st);
 }

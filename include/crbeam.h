@@ -95,6 +95,19 @@ typedef struct crb_input_desc {
     const void* f_held;  /* device [B][n_node][4] or NULL */
 } crb_input_desc;
 
+/* Strided on-device recording of one DOF during crb_step_rk4_rec: the `t_eval` output of the
+ * reference's solve_ivp calls (example_utilities.py:153-159) reduced to what the examples read
+ * (tip displacement, lqr_control.py:168; example_utilities.py:173-205).  After every `every`-th step
+ * out[b][k] = x[b][plane][node][dof], k = (step+1)/every - 1; out holds floor(n_steps/every)
+ * values per beam (device, plan dtype). */
+typedef struct crb_record_desc {
+    int32_t plane;   /* 0 position, 1 velocity */
+    int32_t node;
+    int32_t dof;
+    int32_t every;   /* >= 1 */
+    void* out;       /* device [B][floor(n_steps/every)] */
+} crb_record_desc;
+
 int crb_version(void);
 const char* crb_last_error(void);
 
@@ -161,6 +174,10 @@ int crb_step_rk4(const crb_plan* plan, void* x, double t0, double dt, int n_step
  * Stage 0 passes xs == x.  x, xs, acc, xs_next: device [B][2][n_node][4]; xs_next may not alias xs. */
 int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage,
                   int stage, double t_stage, double dt, const crb_input_desc* input, void* stream);
+
+/* crb_step_rk4 plus strided recording of one DOF (rec may be NULL). */
+int crb_step_rk4_rec(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const crb_input_desc* input,
+                     const crb_record_desc* rec, double* t_end, void* stream);
 
 /* out[b] = x[b][plane][node][dof]  (e.g. tip displacement = plane 0, node n_elem, dof 1;
  * lqr_control.py:168) */

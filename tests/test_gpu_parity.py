@@ -323,3 +323,24 @@ def test_lqr_feedback_rollout_matches_reference(golden, name):
     for b in range(B):
         want = ob.rk4_feedback(np.zeros(2 * n), dt, 300, gain, reference=ref[b], amp=amps[b])
         assert rel_err(got[b], want) < 1e-9
+
+
+@pytest.mark.parametrize("lean", [True, False])
+def test_strided_recording_matches_chunked_stepping(lean):
+    """f-4: on-device t_eval-style recording of the tip displacement / velocity."""
+    # (the shipped nonlinear element under a distributed load diverges within ~250 steps -- SURVEY App. B-1 --
+    #  so the gravity variant, which takes the generic kernel, uses linear elements)
+    cols = nitinol_columns(64, "nonlinear" if lean else "linear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=not lean)
+    amps = np.array([0.1, 0.17, 0.2])
+    a, b = ensemble(cols, 3, kw), ensemble(cols, 3, kw)
+    t, rec = a.step(600, 2e-5, impulse_amp=amps, record=(64, "w"), record_every=50)
+    assert rec.shape == (3, 12)
+    want = []
+    for _ in range(12):
+        b.step(50, 2e-5, impulse_amp=amps)
+        want.append(b.tip_displacement().clone())
+    assert torch.equal(rec, torch.stack(want, dim=1)) and torch.equal(a.state, b.state) and t == b.time
+    _, recv = a.step(30, 2e-5, impulse_amp=amps, record=(10, "dphi_dt"), record_every=7)
+    assert recv.shape == (3, 4)
+    assert torch.equal(recv[:, -1] != 0, torch.ones(3, dtype=torch.bool, device=recv.device))
