@@ -94,6 +94,7 @@ def load():
     L.crb_version.restype = i32
     L.crb_last_error.restype = C.c_char_p
     L.crb_plan_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(BeamDesc)]
+    L.crb_plan_create_ensemble.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(BeamDesc)]
     L.crb_plan_destroy.argtypes = [vp]
     L.crb_plan_destroy.restype = None
     L.crb_plan_get_layout.argtypes = [vp, C.POINTER(Layout)]
@@ -129,46 +130,66 @@ def node_bc_from_column(boundary_condition):
     return np.asarray(codes + [CRB_BC_NONE], dtype=np.uint8)
 
 
+def _beam_desc(columns, node_bc, fluid_density, enable_fluid, gravity, enable_gravity, corrected_axial):
+    """crb_beam_desc for one beam + the numpy arrays it points into (keep them alive)."""
+    f8 = lambda v: np.ascontiguousarray(v, dtype=np.float64)  # noqa: E731
+    cols = {k: f8(columns[k]) for k in ("length", "elastic_modulus", "moment_inertia", "density", "cross_area")}
+    n = cols["length"].shape[0]
+    bad = [str(t) for t in columns["type"] if str(t).lower() not in ("linear", "nonlinear")]
+    if bad:
+        raise ValueError(f"Invalid element types: {set(bad)}")
+    nl = np.ascontiguousarray([1 if str(t).lower() == "nonlinear" else 0 for t in columns["type"]], dtype=np.uint8)
+    if node_bc is None:
+        node_bc = node_bc_from_column(columns["boundary_condition"])
+    bc = np.ascontiguousarray(node_bc, dtype=np.uint8)
+    if bc.shape != (n + 1,):
+        raise ValueError("node_bc must have n_elem + 1 entries")
+    has_fluid_cols = "wetted_area" in columns and "drag_coef" in columns and columns["wetted_area"] is not None
+    wet = f8(columns["wetted_area"]) if has_fluid_cols else None
+    cd = f8(columns["drag_coef"]) if has_fluid_cols else None
+    d = BeamDesc()
+    d.n_elem = n
+    for k, a in cols.items():
+        setattr(d, k, a.ctypes.data_as(_dp))
+    d.nonlinear = nl.ctypes.data_as(_u8p)
+    d.node_bc = bc.ctypes.data_as(_u8p)
+    d.wetted_area = wet.ctypes.data_as(_dp) if wet is not None else None
+    d.drag_coef = cd.ctypes.data_as(_dp) if cd is not None else None
+    d.fluid_density = float(fluid_density)
+    g = np.asarray(gravity, dtype=np.float64)
+    d.gravity[0], d.gravity[1], d.gravity[2] = float(g[0]), float(g[1]), float(g[2])
+    d.flags = ((CRB_FORCE_DRAG if enable_fluid else 0) | (CRB_FORCE_GRAVITY if enable_gravity else 0)
+               | (CRB_CORRECTED_AXIAL if corrected_axial else 0))
+    return d, (cols, nl, bc, wet, cd)
+
+
 class Plan:
-    """Owner of one ``crb_plan`` (one beam topology x n_beams, one dtype, one device)."""
+    """Owner of one ``crb_plan`` (one beam topology x n_beams, one dtype, one device).
+
+    ``columns``: the CSV columns of the beam (dict) -- coefficients shared by all beams -- or a
+    list of n_beams such dicts for per-beam coefficients (crb_plan_create_ensemble)."""
 
     def __init__(self, columns, n_beams=1, node_bc=None, fluid_density=0.0, enable_fluid=False,
                  gravity=(0.0, -9.81, 0.0), enable_gravity=False, corrected_axial=False, dtype="f64", device=0):
         L = load()
-        f8 = lambda v: np.ascontiguousarray(v, dtype=np.float64)  # noqa: E731
-        self._cols = {k: f8(columns[k]) for k in ("length", "elastic_modulus", "moment_inertia", "density",
-                                                  "cross_area")}
-        n = self._cols["length"].shape[0]
-        self._nl = np.ascontiguousarray([1 if str(t).lower() == "nonlinear" else 0 for t in columns["type"]],
-                                        dtype=np.uint8)
-        bad = [str(t) for t in columns["type"] if str(t).lower() not in ("linear", "nonlinear")]
-        if bad:
-            raise ValueError(f"Invalid element types: {set(bad)}")
-        if node_bc is None:
-            node_bc = node_bc_from_column(columns["boundary_condition"])
-        self._bc = np.ascontiguousarray(node_bc, dtype=np.uint8)
-        if self._bc.shape != (n + 1,):
-            raise ValueError("node_bc must have n_elem + 1 entries")
-        has_fluid_cols = "wetted_area" in columns and "drag_coef" in columns and columns["wetted_area"] is not None
-        self._wet = f8(columns["wetted_area"]) if has_fluid_cols else None
-        self._cd = f8(columns["drag_coef"]) if has_fluid_cols else None
-        d = BeamDesc()
-        d.n_elem = n
-        for k, a in self._cols.items():
-            setattr(d, k, a.ctypes.data_as(_dp))
-        d.nonlinear = self._nl.ctypes.data_as(_u8p)
-        d.node_bc = self._bc.ctypes.data_as(_u8p)
-        d.wetted_area = self._wet.ctypes.data_as(_dp) if self._wet is not None else None
-        d.drag_coef = self._cd.ctypes.data_as(_dp) if self._cd is not None else None
-        d.fluid_density = float(fluid_density)
-        g = np.asarray(gravity, dtype=np.float64)
-        d.gravity[0], d.gravity[1], d.gravity[2] = float(g[0]), float(g[1]), float(g[2])
-        d.flags = ((CRB_FORCE_DRAG if enable_fluid else 0) | (CRB_FORCE_GRAVITY if enable_gravity else 0)
-                   | (CRB_CORRECTED_AXIAL if corrected_axial else 0))
+        args = (node_bc, fluid_density, enable_fluid, gravity, enable_gravity, corrected_axial)
         self.dtype = {"f64": CRB_F64, "f32": CRB_F32, CRB_F64: CRB_F64, CRB_F32: CRB_F32}[dtype]
         self.device = int(device)
         h = C.c_void_p()
-        check(L.crb_plan_create(C.byref(h), self.device, self.dtype, int(n_beams), C.byref(d)))
+        if isinstance(columns, (list, tuple)):
+            if len(columns) != n_beams:
+                raise ValueError("per-beam coefficients need exactly n_beams column sets")
+            descs = (BeamDesc * n_beams)()
+            self._keep = []
+            for b, cols in enumerate(columns):
+                descs[b], keep = _beam_desc(cols, *args)
+                self._keep.append(keep)
+            self.per_beam = True
+            check(L.crb_plan_create_ensemble(C.byref(h), self.device, self.dtype, int(n_beams), descs))
+        else:
+            d, self._keep = _beam_desc(columns, *args)
+            self.per_beam = False
+            check(L.crb_plan_create(C.byref(h), self.device, self.dtype, int(n_beams), C.byref(d)))
         self.h = h
         lay = Layout()
         check(L.crb_plan_get_layout(self.h, C.byref(lay)))

@@ -61,7 +61,13 @@ class BeamEnsemble:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
-        self.columns = _columns(parameters, fp.enable_fluid_effects)
+        if isinstance(parameters, (list, tuple)):
+            # heterogeneous ensemble: one parameter set per beam (same topology, per-beam coefficients)
+            if len(parameters) != n_beams:
+                raise ValueError("a list of parameter sets must have n_beams entries")
+            self.columns = [_columns(p, fp.enable_fluid_effects) for p in parameters]
+        else:
+            self.columns = _columns(parameters, fp.enable_fluid_effects)
         self.plan = nat.Plan(self.columns, n_beams=n_beams, node_bc=node_bc, fluid_density=fp.fluid_density,
                              enable_fluid=fp.enable_fluid_effects, gravity=fp.get_gravity_vector(),
                              enable_gravity=fp.enable_gravity_effects, corrected_axial=corrected_axial,

@@ -61,6 +61,8 @@ struct KParams {
     T* rec_out;                // MODE_STEP: [B][n_rec] strided record of one DOF, or nullptr
     int rec_slot, rec_comp;    // recording thread (slot) and component 0..5 of {q, v}
     int rec_every, rec_n;
+    // per-beam coefficient mode (heterogeneous ensembles): table offsets per beam, in elements; 0 = shared
+    size_t slot_stride, lv_stride, fin_stride;
     int B, S, G, n_node, off, levels;
     int lognw;                 // log2(wavefronts per beam); 0 when a wave holds whole beams
     uint32_t flags;
@@ -258,15 +260,15 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
     SlotConst<T> sc;
     SolveCoef<T, LV> cf;
     if (valid) {
-        sc = p.slot[tp.j];
+        sc = p.slot[size_t(beam) * p.slot_stride + tp.j];
 #pragma unroll
         for (int l = 0; l < LV; ++l) {
-            const T* src = p.pcr_levels + (size_t(l) * size_t(p.S) + size_t(tp.j)) * PCR_LEVEL_VALS;
+            const T* src = p.pcr_levels + size_t(beam) * p.lv_stride + (size_t(l) * size_t(p.S) + size_t(tp.j)) * PCR_LEVEL_VALS;
 #pragma unroll
             for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
         }
 #pragma unroll
-        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(tp.j) * PCR_FINAL_VALS + k];
+        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(beam) * p.fin_stride + size_t(tp.j) * PCR_FINAL_VALS + k];
     } else {
         sc.elem.kind = KIND_NONE;
 #pragma unroll
@@ -535,17 +537,17 @@ __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KPa
     T dragc = T(0);
     SolveCoef<T, LV> cf;
     if (valid) {
-        const SlotConst<T>& sc = p.slot[j];
+        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];
         ec = sc.elem;
         dragc = (p.flags & 1u) ? sc.drag : T(0);
 #pragma unroll
         for (int l = 0; l < LV; ++l) {
-            const T* src = p.pcr_levels + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+            const T* src = p.pcr_levels + size_t(beam) * p.lv_stride + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
 #pragma unroll
             for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
         }
 #pragma unroll
-        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(j) * PCR_FINAL_VALS + k];
+        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(beam) * p.fin_stride + size_t(j) * PCR_FINAL_VALS + k];
     } else {
         ec.kind = KIND_NONE;
 #pragma unroll
@@ -566,7 +568,7 @@ __global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KPa
     T xq[3] = {T(0), T(0), T(0)}, xv[3] = {T(0), T(0), T(0)};
     T amp = T(0);
     if (valid) {
-        const SlotConst<T>& sc = p.slot[j];
+        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             xq[c] = p.x[xoff + c] * sc.mask[c];
@@ -742,11 +744,15 @@ struct AsmParams {
     double fluid_density;
     uint32_t flags;
     int n_elem, n_node, off, S, levels_full;
-    void* slot_out;             // SlotConst<T>[S]
-    double* lv64; void* lvT;    // [levels_full][S][10]
-    double* fin64_all;          // [levels_full+1][S][6]  final inverse after k levels, k = 0..levels_full
-    double* norms;              // [levels_full]  (must be zeroed before launch)
-    double* blocks0;            // [S][15] node blocks before reduction (dense-mass inspection)
+    void* slot_out;             // SlotConst<T>[nb][S]
+    double* lv64; void* lvT;    // [nb][levels_full][S][10]   (lv64 may be null)
+    double* fin64_all;          // [levels_full+1][S][6] final inverse after k levels (beam 0 only; may be null)
+    void* finT;                 // [nb][S][6] final inverse after `fin_level` levels, plan dtype (may be null)
+    int fin_level;
+    double* norms;              // [levels_full]  max over beams (must be zeroed before launch)
+    double* blocks0;            // [S][15] node blocks before reduction (beam 0 only; may be null)
+    // one workgroup per beam; element columns are [nb][n_elem] with this stride (0 = one shared beam)
+    size_t elem_stride;
 };
 
 __device__ __forceinline__ void atomic_max_nonneg(double* addr, double v) {
@@ -759,9 +765,15 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     NodeBlocks* sh = reinterpret_cast<NodeBlocks*>(crb_smem);  // [S]
     const int j = threadIdx.x;
+    const int beam = blockIdx.x;
     const bool valid = j < p.S;
     const int node = j + p.off, ne = p.n_elem, nn = p.n_node;
     auto fm = [&](int nd, int c) { return nd >= 0 && nd < nn && p.free_dof[3 * nd + c] != 0; };
+    const size_t eo = size_t(beam) * p.elem_stride;
+    const double *pL = p.L + eo, *pE = p.E + eo, *pI = p.I + eo, *pRho = p.rho + eo, *pA = p.A + eo;
+    const uint8_t* pNl = p.nonlinear + eo;
+    const double *pWet = p.wet ? p.wet + eo : nullptr, *pCd = p.cd ? p.cd + eo : nullptr;
+    const size_t tab = size_t(beam) * size_t(p.S);  // this beam's first slot in the per-beam tables
 
     NodeBlocks cur;
     for (int k = 0; k < 4; ++k) cur.A[k] = cur.B[k] = cur.C[k] = 0.0;
@@ -773,8 +785,8 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
         const int e = node - 1;
         int kind = KIND_NONE;
         if (e >= 0) {
-            kind = p.nonlinear[e] ? KIND_NONLINEAR : KIND_LINEAR;
-            elem_coef_build<T>(sc.elem, kind, p.L[e], p.E[e], p.I[e], p.A[e]);
+            kind = pNl[e] ? KIND_NONLINEAR : KIND_LINEAR;
+            elem_coef_build<T>(sc.elem, kind, pL[e], pE[e], pI[e], pA[e]);
         } else {
             elem_coef_build<T>(sc.elem, KIND_NONE, 1.0, 1.0, 1.0, 1.0);
         }
@@ -783,24 +795,26 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
         sc.drag = T(0);
         if ((p.flags & 1u) && fm(node, 1)) {
             const int row = node < ne ? node : ne - 1;
-            sc.drag = T(0.5 * p.fluid_density * p.cd[row] * p.wet[row]);
+            sc.drag = T(0.5 * p.fluid_density * pCd[row] * pWet[row]);
         }
-        sc.half_mass = ((p.flags & 2u) && j < ne) ? T(0.5 * (p.rho[j] * p.A[j] * p.L[j])) : T(0);
+        sc.half_mass = ((p.flags & 2u) && j < ne) ? T(0.5 * (pRho[j] * pA[j] * pL[j])) : T(0);
         sc.grav = p.grav[j];
-        static_cast<SlotConst<T>*>(p.slot_out)[j] = sc;
+        static_cast<SlotConst<T>*>(p.slot_out)[tab + j] = sc;
 
         // ---- mass matrix, node-block form, with the boundary-condition masks
         const int el = node - 1, er = node;
-        if (el >= 0) mass_add_as_left_elem(cur, p.L[el], p.rho[el] * p.A[el], j >= 1);
-        if (er < ne) mass_add_as_right_elem(cur, p.L[er], p.rho[er] * p.A[er]);
+        if (el >= 0) mass_add_as_left_elem(cur, pL[el], pRho[el] * pA[el], j >= 1);
+        if (er < ne) mass_add_as_right_elem(cur, pL[er], pRho[er] * pA[er]);
         const bool hl = j >= 1, hr = j + 1 < p.S;
         mass_apply_masks(cur, fm(node, 0), fm(node, 1), fm(node, 2), hl && fm(node - 1, 0), hl && fm(node - 1, 1),
                          hl && fm(node - 1, 2), hr && fm(node + 1, 0), hr && fm(node + 1, 1), hr && fm(node + 1, 2));
-        double* b0 = p.blocks0 + size_t(j) * 15;
-        b0[0] = cur.a_ax; b0[1] = cur.b_ax; b0[2] = cur.c_ax;
-        for (int k = 0; k < 4; ++k) { b0[3 + k] = cur.A[k]; b0[7 + k] = cur.B[k]; b0[11 + k] = cur.C[k]; }
+        if (p.blocks0 && beam == 0) {
+            double* b0 = p.blocks0 + size_t(j) * 15;
+            b0[0] = cur.a_ax; b0[1] = cur.b_ax; b0[2] = cur.c_ax;
+            for (int k = 0; k < 4; ++k) { b0[3 + k] = cur.A[k]; b0[7 + k] = cur.B[k]; b0[11 + k] = cur.C[k]; }
+        }
         const int elc = node - 1 >= 0 ? node - 1 : 0;
-        Lc = p.L[elc < ne ? elc : ne - 1];
+        Lc = pL[elc < ne ? elc : ne - 1];
     }
 
     // ---- cyclic-reduction factorisation, one level per iteration
@@ -808,14 +822,13 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
         if (valid) {
             double Bi[4];
             inv2(cur.B, Bi);
-            double* o = p.fin64_all + (size_t(l) * p.S + j) * PCR_FINAL_VALS;
             const double mu = fm(node, 0) ? 1.0 : 0.0, mw = fm(node, 1) ? 1.0 : 0.0, mp = fm(node, 2) ? 1.0 : 0.0;
-            o[0] = mu / cur.b_ax;
-            o[1] = mw * mw * Bi[0];
-            o[2] = mw * mp * Bi[1];
-            o[3] = mp * mw * Bi[2];
-            o[4] = mp * mp * Bi[3];
-            o[5] = 0.0;
+            const double fin[PCR_FINAL_VALS] = {mu / cur.b_ax, mw * mw * Bi[0], mw * mp * Bi[1], mp * mw * Bi[2],
+                                                mp * mp * Bi[3], 0.0};
+            if (p.fin64_all && beam == 0)
+                for (int k = 0; k < PCR_FINAL_VALS; ++k) p.fin64_all[(size_t(l) * p.S + j) * PCR_FINAL_VALS + k] = fin[k];
+            if (p.finT && l == p.fin_level)
+                for (int k = 0; k < PCR_FINAL_VALS; ++k) static_cast<T*>(p.finT)[(tab + j) * PCR_FINAL_VALS + k] = T(fin[k]);
             sh[j] = cur;
         }
         if (l == p.levels_full) break;
@@ -827,11 +840,11 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
             const bool hl = j - s >= 0, hh = j + s < p.S;
             const NodeBlocks lo = sh[hl ? j - s : j], hi = sh[hh ? j + s : j];
             pcr_factor_level(cur, lo, hl, hi, hh, lv, nxt);
-            const size_t o = (size_t(l) * p.S + j) * PCR_LEVEL_VALS;
+            const size_t o = ((size_t(beam) * p.levels_full + l) * p.S + j) * PCR_LEVEL_VALS;
             double vals[PCR_LEVEL_VALS] = {lv.al_ax, lv.ga_ax, lv.al[0], lv.al[1], lv.al[2], lv.al[3],
                                            lv.ga[0], lv.ga[1], lv.ga[2], lv.ga[3]};
             for (int k = 0; k < PCR_LEVEL_VALS; ++k) {
-                p.lv64[o + k] = vals[k];
+                if (p.lv64 && beam == 0) p.lv64[(size_t(l) * p.S + j) * PCR_LEVEL_VALS + k] = vals[k];
                 static_cast<T*>(p.lvT)[o + k] = T(vals[k]);
             }
             atomic_max_nonneg(p.norms + l, pcr_level_norm(lv, Lc));

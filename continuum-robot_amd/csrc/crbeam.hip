@@ -29,6 +29,7 @@ struct crb_plan {
     int device = -1, dtype = CRB_F64, B = 0;
     int n_elem = 0, n_node = 0, n_free = 0, off = 0, S = 0, G = 1, NT = 64;
     int levels = 0, levels_full = 0, lognw = 0;
+    size_t slot_stride = 0, lv_stride = 0, fin_stride = 0;  // per-beam coefficient tables (0 = shared)
     uint32_t flags = 0;
     double gx = 0, gy = 0;
     std::vector<int32_t> free_index;  // reduced -> full
@@ -113,31 +114,50 @@ int pick_levels(crb_plan* p) {
     return used;
 }
 
-// Runs crb_assemble_kernel on the plan's device and fills both the device tables the steppers
-// load and the host copies the crb_plan_get_* inspectors return.
+// Runs crb_assemble_kernel on the plan's device (one workgroup per described beam) and fills both
+// the device tables the steppers load and, for beam 0, the host copies the crb_plan_get_* inspectors
+// return.  nd == 1: coefficients shared by all beams of the plan; nd == n_beams: per-beam coefficients.
 template <typename T>
-int device_assemble(crb_plan* p, const crb_beam_desc* d, const std::vector<SlotConst<double>>& slots,
+int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::vector<SlotConst<double>>& slots,
                     const std::vector<uint8_t>& free_dof) {
     const int S = p->S, ne = p->n_elem, lf = p->levels_full;
+    const crb_beam_desc* d = descs;
     DevBuf<double> dL, dE, dI, dRho, dA, dWet, dCd, dFinAll, dNorms, dBlocks, dLv64;
     DevBuf<uint8_t> dNl, dFree;
     DevBuf<GravTab> dGrav;
     std::vector<GravTab> grav(S);
     for (int j = 0; j < S; ++j) grav[j] = slots[j].grav;
     const bool drag = d->flags & CRB_FORCE_DRAG;
-    if (dL.upload(d->length, ne) || dE.upload(d->elastic_modulus, ne) || dI.upload(d->moment_inertia, ne) ||
-        dRho.upload(d->density, ne) || dA.upload(d->cross_area, ne) || dNl.upload(d->nonlinear, ne) ||
+    // element columns, [nd][n_elem]
+    auto gather = [&](const double* crb_beam_desc::*col) {
+        std::vector<double> v(size_t(nd) * ne);
+        for (int b = 0; b < nd; ++b) std::memcpy(&v[size_t(b) * ne], descs[b].*col, size_t(ne) * sizeof(double));
+        return v;
+    };
+    std::vector<uint8_t> nl(size_t(nd) * ne);
+    for (int b = 0; b < nd; ++b) std::memcpy(&nl[size_t(b) * ne], descs[b].nonlinear, size_t(ne));
+    const auto vL = gather(&crb_beam_desc::length), vE = gather(&crb_beam_desc::elastic_modulus),
+               vI = gather(&crb_beam_desc::moment_inertia), vR = gather(&crb_beam_desc::density),
+               vA = gather(&crb_beam_desc::cross_area);
+    std::vector<double> vW, vC;
+    if (drag) { vW = gather(&crb_beam_desc::wetted_area); vC = gather(&crb_beam_desc::drag_coef); }
+    if (dL.upload(vL.data(), vL.size()) || dE.upload(vE.data(), vE.size()) || dI.upload(vI.data(), vI.size()) ||
+        dRho.upload(vR.data(), vR.size()) || dA.upload(vA.data(), vA.size()) || dNl.upload(nl.data(), nl.size()) ||
         dFree.upload(free_dof.data(), free_dof.size()) || dGrav.upload(grav.data(), S) ||
-        (drag && (dWet.upload(d->wetted_area, ne) || dCd.upload(d->drag_coef, ne))) ||
+        (drag && (dWet.upload(vW.data(), vW.size()) || dCd.upload(vC.data(), vC.size()))) ||
         dFinAll.alloc(size_t(lf + 1) * S * PCR_FINAL_VALS) || dNorms.alloc(lf) || dBlocks.alloc(size_t(S) * 15) ||
         dLv64.alloc(size_t(lf) * S * PCR_LEVEL_VALS))
         return fail(CRB_EHIP, "crb_plan_create: device allocation/upload failed");
-    HIP_TRY(hipMalloc(&p->d_slot, size_t(S) * sizeof(SlotConst<T>)));
-    HIP_TRY(hipMalloc(&p->d_levels, size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
-    HIP_TRY(hipMalloc(&p->d_final, size_t(S) * PCR_FINAL_VALS * sizeof(T)));
+    HIP_TRY(hipMalloc(&p->d_slot, size_t(nd) * S * sizeof(SlotConst<T>)));
+    HIP_TRY(hipMalloc(&p->d_levels, size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
+    HIP_TRY(hipMalloc(&p->d_final, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), p->free_index.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->d_free_index, p->free_index.data(), p->free_index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dNorms.p, 0, size_t(lf ? lf : 1) * sizeof(double)));
+    if (nd > 1) {
+        p->slot_stride = size_t(S);
+        p->lv_stride = size_t(lf) * S * PCR_LEVEL_VALS;
+        p->fin_stride = size_t(S) * PCR_FINAL_VALS;
+    }
 
     AsmParams a;
     std::memset(&a, 0, sizeof(a));
@@ -146,17 +166,18 @@ int device_assemble(crb_plan* p, const crb_beam_desc* d, const std::vector<SlotC
     a.fluid_density = d->fluid_density; a.flags = d->flags;
     a.n_elem = ne; a.n_node = p->n_node; a.off = p->off; a.S = S; a.levels_full = lf;
     a.slot_out = p->d_slot; a.lv64 = dLv64.p; a.lvT = p->d_levels; a.fin64_all = dFinAll.p; a.norms = dNorms.p;
-    a.blocks0 = dBlocks.p;
+    a.blocks0 = dBlocks.p; a.finT = nullptr; a.fin_level = -1;
+    a.elem_stride = nd > 1 ? size_t(ne) : 0;
     const int nta = (S + 63) / 64 * 64;
     const size_t smem = size_t(S) * sizeof(NodeBlocks);
     if (smem > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&crb_assemble_kernel<T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-    hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(1), dim3(nta), smem, nullptr, a);
+    // pass 1: constants, multipliers of every level, their norms (max over beams)
+    HIP_TRY(hipMemset(dNorms.p, 0, size_t(lf ? lf : 1) * sizeof(double)));
+    hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(nta), smem, nullptr, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-
-    // ---- read back: inspection copies + the level count decision
     p->h_levels.assign(size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS, 0.0);
     p->h_norms.assign(size_t(lf > 0 ? lf : 1), 0.0);
     if (lf > 0) {
@@ -166,12 +187,16 @@ int device_assemble(crb_plan* p, const crb_beam_desc* d, const std::vector<SlotC
     const int used = pick_levels(p);
     if (used > MAX_LV)
         return fail(CRB_EUNSUPPORTED, "mass matrix needs more cyclic-reduction levels than the kernels carry in registers");
+    // pass 2: the final inverses after `used` levels, straight into the steppers' table
+    a.finT = p->d_final; a.fin_level = used; a.lv64 = nullptr; a.blocks0 = nullptr; a.fin64_all = nullptr;
+    hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(nta), smem, nullptr, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+
+    // ---- inspection copies (beam 0)
     p->h_final.assign(size_t(S) * PCR_FINAL_VALS, 0.0);
     HIP_TRY(hipMemcpy(p->h_final.data(), dFinAll.p + size_t(used) * S * PCR_FINAL_VALS,
                       size_t(S) * PCR_FINAL_VALS * sizeof(double), hipMemcpyDeviceToHost));
-    std::vector<T> fin(size_t(S) * PCR_FINAL_VALS);
-    for (size_t i = 0; i < fin.size(); ++i) fin[i] = T(p->h_final[i]);
-    HIP_TRY(hipMemcpy(p->d_final, fin.data(), fin.size() * sizeof(T), hipMemcpyHostToDevice));
     std::vector<double> b0(size_t(S) * 15);
     HIP_TRY(hipMemcpy(b0.data(), dBlocks.p, b0.size() * sizeof(double), hipMemcpyDeviceToHost));
     std::vector<NodeBlocks> blk(S);
@@ -199,13 +224,47 @@ int device_assemble(crb_plan* p, const crb_beam_desc* d, const std::vector<SlotC
 
 }  // namespace
 
+static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* d, int nd);
+
 extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* d) {
+    return plan_create_impl(out, device, dtype, n_beams, d, 1);
+}
+
+extern "C" int crb_plan_create_ensemble(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* descs) {
+    if (!out || !descs) return fail(CRB_EINVAL, "crb_plan_create_ensemble: null argument");
+    if (n_beams < 1) return fail(CRB_EINVAL, "n_beams must be >= 1");
+    if (device < 0) return fail(CRB_EUNSUPPORTED, "per-beam coefficient plans are built on the device (no host-only form)");
+    const crb_beam_desc& a = descs[0];
+    for (int b = 1; b < n_beams; ++b) {
+        const crb_beam_desc& d = descs[b];
+        if (d.n_elem != a.n_elem || d.flags != a.flags || d.fluid_density != a.fluid_density ||
+            d.gravity[0] != a.gravity[0] || d.gravity[1] != a.gravity[1] || !d.node_bc || !a.node_bc ||
+            std::memcmp(d.node_bc, a.node_bc, size_t(a.n_elem) + 1) != 0)
+            return fail(CRB_EINVAL, "ensemble beams must share n_elem, boundary conditions and force parameters");
+    }
+    return plan_create_impl(out, device, dtype, n_beams, descs, n_beams);
+}
+
+static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* d, int nd) {
     if (!out || !d) return fail(CRB_EINVAL, "crb_plan_create: null argument");
     *out = nullptr;
     if (dtype != CRB_F64 && dtype != CRB_F32) return fail(CRB_EINVAL, "dtype must be CRB_F64 or CRB_F32");
     if (n_beams < 1) return fail(CRB_EINVAL, "n_beams must be >= 1");
     const int ne = d->n_elem;
     if (ne < 1) return fail(CRB_EINVAL, "n_elem must be >= 1");
+    for (int b = 1; b < nd; ++b) {  // the other beams of a per-beam-coefficient ensemble
+        const crb_beam_desc& o = d[b];
+        if (!o.length || !o.elastic_modulus || !o.moment_inertia || !o.density || !o.cross_area || !o.nonlinear)
+            return fail(CRB_EINVAL, "beam description has null columns");
+        for (int e = 0; e < ne; ++e) {
+            if (!(o.length[e] > 0) || !(o.elastic_modulus[e] > 0) || !(o.moment_inertia[e] > 0) || !(o.density[e] > 0) ||
+                !(o.cross_area[e] > 0))
+                return fail(CRB_EINVAL, "All numeric parameters must be positive");
+            if (o.nonlinear[e] > 1) return fail(CRB_EINVAL, "Invalid element type");
+            if ((o.flags & CRB_FORCE_DRAG) && (!o.wetted_area || !o.drag_coef || o.drag_coef[e] < 0 || o.wetted_area[e] < 0))
+                return fail(CRB_EINVAL, "Drag coefficients / wetted areas missing or negative");
+        }
+    }
     if (!d->length || !d->elastic_modulus || !d->moment_inertia || !d->density || !d->cross_area || !d->nonlinear ||
         !d->node_bc)
         return fail(CRB_EINVAL, "beam description has null columns");
@@ -409,8 +468,8 @@ extern "C" int crb_plan_create(crb_plan** out, int device, int dtype, int n_beam
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete p; return fail(CRB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
         // ======== device plan: crb_assemble_kernel builds every floating-point table ========
-        const int rc = (dtype == CRB_F64) ? device_assemble<double>(p, d, slots, free_dof)
-                                          : device_assemble<float>(p, d, slots, free_dof);
+        const int rc = (dtype == CRB_F64) ? device_assemble<double>(p, d, nd, slots, free_dof)
+                                          : device_assemble<float>(p, d, nd, slots, free_dof);
         if (rc != CRB_OK) { crb_plan_destroy(p); return rc; }
     }
     *out = p;
@@ -522,6 +581,7 @@ KParams<T> base_params(const crb_plan* p) {
     k.off = p->off;
     k.levels = p->levels;
     k.lognw = p->lognw;
+    k.slot_stride = p->slot_stride; k.lv_stride = p->lv_stride; k.fin_stride = p->fin_stride;
     k.flags = p->flags;
     k.imp_slot = -1;
     k.imp_dof = 0;

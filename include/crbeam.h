@@ -119,6 +119,11 @@ const char* crb_last_error(void);
  * device >= 0: HIP device ordinal, tables are uploaded.  device == -1: host-only plan for
  * inspection (crb_plan_get_* work, every launch returns CRB_ENODEV). */
 int crb_plan_create(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* desc);
+/* Per-beam coefficients (heterogeneous ensembles, SURVEY f-3): descs[n_beams], one CSV-schema record
+ * per beam.  All beams must share n_elem, node_bc, flags, fluid_density and gravity; every element
+ * column (and the linear/nonlinear type) may differ per beam.  Assembly and factorisation run
+ * batched on the device (one workgroup per beam); the inspectors (crb_plan_get_*) describe beam 0. */
+int crb_plan_create_ensemble(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* descs);
 void crb_plan_destroy(crb_plan* plan);
 int crb_plan_get_layout(const crb_plan* plan, crb_layout* out);
 /* reduced index -> full index 3*node+dof, ascending (euler_bernoulli_beam.py:258-259); [n_free] host */

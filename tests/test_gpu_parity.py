@@ -344,3 +344,47 @@ def test_strided_recording_matches_chunked_stepping(lean):
     _, recv = a.step(30, 2e-5, impulse_amp=amps, record=(10, "dphi_dt"), record_every=7)
     assert recv.shape == (3, 4)
     assert torch.equal(recv[:, -1] != 0, torch.ones(3, dtype=torch.bool, device=recv.device))
+
+
+def _scaled(cols, rng):
+    """Per-beam E, rho, r scaled by U(0.9, 1.1) (SURVEY §8(d) heterogeneous variant)."""
+    sE, sr, srho = rng.uniform(0.9, 1.1, 3)
+    out = dict(cols)
+    out["elastic_modulus"] = cols["elastic_modulus"] * sE
+    out["density"] = cols["density"] * srho
+    out["cross_area"] = cols["cross_area"] * sr**2
+    out["moment_inertia"] = cols["moment_inertia"] * sr**4
+    out["wetted_area"] = cols["wetted_area"] * sr
+    return out
+
+
+@pytest.mark.parametrize("n_e,kind,kw", [
+    (64, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True)),           # lean stepper, one wave
+    (256, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True)),          # lean stepper, four waves
+    (40, "linear", dict(enable_gravity=True, fluid_density=500.0, enable_fluid=True)),  # generic stepper
+    (10, "linear", dict(enable_gravity=True)),                                  # several beams per wave
+])
+def test_heterogeneous_ensemble_matches_per_beam_oracle(n_e, kind, kw):
+    """f-3: per-beam coefficients (crb_plan_create_ensemble, batched device assembly)."""
+    rng = np.random.default_rng(4321)
+    B = 9
+    base = nitinol_columns(n_e, kind)
+    per_beam = [_scaled(base, rng) for _ in range(B)]
+    if kind == "linear":  # per-beam element TYPES too
+        per_beam[3]["type"] = np.array(["nonlinear" if i % 2 else "linear" for i in range(n_e)])
+    amps = 0.1 * (1.0 + np.arange(B) / B)
+    ens = ensemble(per_beam, B, kw)
+    steps = 150
+    ens.step(steps, 2e-5, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    for b in range(B):
+        ob = oracle_beam(per_beam[b], **kw)
+        want = ob.rk4_impulse(np.zeros(2 * ob.n), 2e-5, steps, amps[b])
+        assert rel_err(got[b], want) < 1e-9, b
+    # rhs through the per-beam tables as well
+    x = rng.normal(0, 1e-3, (B, 2 * ens.n))
+    xd = ens.rhs(x).cpu().numpy()
+    for b in (0, B - 1):
+        assert rel_err(xd[b], oracle_beam(per_beam[b], **kw).rhs(x[b])) < 1e-10
+    with pytest.raises(Exception, match="share n_elem"):
+        ensemble([base, nitinol_columns(n_e + 1, kind)], 2, kw)
