@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--launch-steps", type=int, default=0, help="RK4 steps fused per launch (0 = all of --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hetero", action="store_true",
+                    help="heterogeneous variant (SURVEY 8(d)): per-beam E, rho, r scaled by U(0.9, 1.1), seed 4321")
     return ap.parse_args()
 
 
@@ -129,8 +131,21 @@ def main():
     fp = ForceParams(fluid_density=1000.0 if cfg["drag"] else 0.0, enable_fluid_effects=cfg["drag"],
                      enable_gravity_effects=cfg["gravity"])
     okw = dict(fluid_density=fp.fluid_density, enable_fluid=cfg["drag"], enable_gravity=cfg["gravity"])
+    params = cols
+    if args.hetero:
+        rng_h = np.random.default_rng(4321 + rank)
+        params = []
+        for _ in range(B):
+            sE, sr, srho = rng_h.uniform(0.9, 1.1, 3)
+            c = dict(cols)
+            c["elastic_modulus"] = cols["elastic_modulus"] * sE
+            c["density"] = cols["density"] * srho
+            c["cross_area"] = cols["cross_area"] * sr**2
+            c["moment_inertia"] = cols["moment_inertia"] * sr**4
+            c["wetted_area"] = cols["wetted_area"] * sr
+            params.append(c)
     t_plan = time.perf_counter()
-    ens = BeamEnsemble(cols, B, force_params=fp, dtype=dtype, device=f"cuda:{local_rank}")
+    ens = BeamEnsemble(params, B, force_params=fp, dtype=dtype, device=f"cuda:{local_rank}")
     torch.cuda.synchronize()
     plan_ms = (time.perf_counter() - t_plan) * 1e3
 
@@ -210,8 +225,8 @@ def main():
     finite = bool(torch.isfinite(state).all())
     check = {"finite": finite, "gathered_beams": int(gathered.shape[0])}
     if rank == 0:
-        ob = oracle_beam(cols, **okw)
         b = B - 1
+        ob = oracle_beam(params[b] if args.hetero else cols, **okw)
         x0b = np.zeros(2 * ob.n) if x0 is None else x0n[b]
         if gain is None:
             ref = ob.rk4_impulse(x0b, dt, args.steps, float(amps[b].item()))
@@ -235,7 +250,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": cfg["label"], "beams_per_gpu": B, "beams_total": B_total, "elements": ne,
+            "config": {"workload": cfg["label"] + (" [heterogeneous: per-beam coefficients]" if args.hetero else ""), "beams_per_gpu": B, "beams_total": B_total, "elements": ne,
                        "dt": dt, "steps_per_launch": min(per_launch, args.steps), "parallelism": f"beam-shard x{world}",
                        "collective": "all_gather_into_tensor(terminal states)" if world > 1 else "none",
                        "plan_ms": plan_ms},
