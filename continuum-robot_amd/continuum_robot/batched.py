@@ -219,14 +219,18 @@ class BeamEnsemble:
 
         gain       [n, 2n] LQR gain (reduced ordering, e.g. LinearQuadraticRegulator.compute_gain_matrix())
         reference  [B, 2n] or None (= regulation to 0)
-        Stage-split path: per stage one GEMM over the whole ensemble, [B, 2n] x [2n, n] (hipBLASLt /
-        rocBLAS through torch.matmul), then one launch of the stage kernel (crb_rk4_stage).
+        Stage-split path: per stage one GEMM over the whole ensemble, [B, 2n] x [2n, n] -- the fused
+        fp64-MFMA kernel crb_feedback_force (gather + GEMM + scatter; fp32 plans go through
+        torch.matmul) -- then one launch of the stage kernel (crb_rk4_stage).
         Note: the LQR loop is stiff (|lambda|max ~ 3e5 1/s for the Nitinol example): RK4 needs
         dt <= ~8e-6 s, not the 2e-5 s of the open-loop configs.
         """
         if t0 is not None:
             self.time = float(t0)
-        Kt = self._dev(gain, (self.n, 2 * self.n)).t().contiguous()
+        K = self._dev(gain, (self.n, 2 * self.n))
+        fused = self.dtype == torch.float64
+        Kt = None if fused else K.t().contiguous()
+        u_buf = torch.zeros((self.n_beams, self.n_node, 4), dtype=self.dtype, device=self.device)
         ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
         desc = nat.InputDesc()
         desc.kind = nat.CRB_INPUT_NONE
@@ -249,15 +253,19 @@ class BeamEnsemble:
                 th, t1 = t + 0.5 * dt, t + dt
                 cur = self.state
                 for s, ts in enumerate((t, th, th, t1)):
-                    xr = self.unpack_state(cur)
-                    err = -xr if ref is None else ref - xr
-                    u_dev = self.pack_vec(err @ Kt)
+                    if fused:
+                        nat.check(self._lib.crb_feedback_force(self.plan.h, self._ptr(cur), self._ptr(K), self._ptr(ref),
+                                                               self._ptr(u_buf), stream))
+                        u_dev = u_buf
+                    else:
+                        xr = self.unpack_state(cur)
+                        u_dev = self.pack_vec((-xr if ref is None else ref - xr) @ Kt)
                     nxt = bufs[s & 1]
                     nat.check(self._lib.crb_rk4_stage(self.plan.h, self._ptr(self.state), self._ptr(cur), self._ptr(acc),
                                                       self._ptr(nxt), self._ptr(u_dev), s, ts, dt, C.byref(desc), stream))
                     cur = nxt
                 t = t1
-        self._keep = [amp, acc, bufs, Kt, ref]
+        self._keep = [amp, acc, bufs, K, Kt, ref, u_buf]
         self.time = t
         return t
 

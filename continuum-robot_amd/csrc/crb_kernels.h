@@ -854,6 +854,108 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
     }
 }
 
+// ------------------------------------------------------------------ feedback force (f-1)
+// crb_feedback_kernel: U = (R - X) K^T for the whole ensemble, the controller of
+// examples/lqr_control.py:95-111 / control/full_state_linear.py:81 (u = K (r - x)) as ONE fp64 GEMM
+//     [B x 2n] . [2n x n]    on v_mfma_f64_16x16x4_f64,
+// with the gather from the device state layout fused into the A-operand load and the scatter into the
+// device force layout fused into the epilogue (no reduced-order copies of the state, no library call).
+// Tile: BM beams x BN outputs per 256-thread workgroup (64 x 64, or 32 x 32 when that is needed to fill the
+// chip), each wave a quarter of it in 16 x 16 MFMA tiles,
+// K step 32 through LDS with the next step's loads in flight.  LDS rows are [row][32 + 2 pad] doubles: the fragment reads
+// (lane l -> row l&15, k = kk + (l>>4)) then touch every bank exactly once.
+// MFMA lane maps (MI355X guide): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// D: col j = l&15, row i = (l>>4) + 4*reg.
+typedef double crb_d4 __attribute__((ext_vector_type(4)));
+struct FeedbackParams {
+    const double* xs;       // [B][2][n_node][4]
+    const double* ref;      // [B][2n] reduced, or nullptr (= 0)
+    const double* gain;     // [n][2n] row-major
+    double* u;              // [B][n_node][4]; only free-DOF entries are written
+    const int32_t* col_off; // [2n] offset of reduced state index j inside a beam's state record
+    const int32_t* row_off; // [n]  offset of reduced position index i inside a beam's force record
+    int B, n, n2;           // n2 = 2n
+    size_t x_stride, u_stride;
+};
+constexpr int FB_BK = 64, FB_LD = FB_BK + 2;
+
+// BM x BN outputs per 256-thread workgroup (4 waves as 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles)
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams p) {
+    constexpr int TM = BM / 32, TN = BN / 32, QA = BM * FB_BK / 256, QB = BN * FB_BK / 256, RSTEP = 256 / FB_BK;
+    __shared__ __attribute__((aligned(16))) double As[BM * FB_LD];
+    __shared__ __attribute__((aligned(16))) double Bs[BN * FB_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    crb_d4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = crb_d4{0.0, 0.0, 0.0, 0.0};
+
+    // loader: this thread fetches column lk of rows lr, lr+8, .. of both tiles; the values of K-step
+    // s+1 are in flight (registers) while the MFMAs of step s run out of LDS
+    const int lk = t & (FB_BK - 1), lr = t / FB_BK;
+    double ea[QA], gb[QB];
+    auto fetch = [&](int k0) {
+        const int k = k0 + lk;
+        const bool kok = k < p.n2;
+        const int coff = kok ? p.col_off[k] : 0;
+#pragma unroll
+        for (int q = 0; q < QA; ++q) {
+            const int b = m0 + lr + RSTEP * q;
+            double e = 0.0;
+            if (kok && b < p.B) {
+                e = -p.xs[size_t(b) * p.x_stride + coff];
+                if (p.ref) e += p.ref[size_t(b) * p.n2 + k];
+            }
+            ea[q] = e;
+        }
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            const int i = n0 + lr + RSTEP * q;
+            gb[q] = (kok && i < p.n) ? p.gain[size_t(i) * p.n2 + k] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < p.n2; k0 += FB_BK) {
+#pragma unroll
+        for (int q = 0; q < QA; ++q) As[(lr + RSTEP * q) * FB_LD + lk] = ea[q];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) Bs[(lr + RSTEP * q) * FB_LD + lk] = gb[q];
+        __syncthreads();
+        if (k0 + FB_BK < p.n2) fetch(k0 + FB_BK);
+#pragma unroll
+        for (int kk = 0; kk < FB_BK; kk += 4) {
+            double af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = As[(wm + 16 * a + (lane & 15)) * FB_LD + kk + (lane >> 4)];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = Bs[(wn + 16 * b + (lane & 15)) * FB_LD + kk + (lane >> 4)];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: D row (beam) = (lane>>4) + 4*reg, D col (output) = lane&15; scatter into the force layout
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int i = n0 + wn + 16 * b + (lane & 15);
+            if (i >= p.n) continue;
+            const int roff = p.row_off[i];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int beam = m0 + wm + 16 * a + (lane >> 4) + 4 * reg;
+                if (beam < p.B) p.u[size_t(beam) * p.u_stride + roff] = acc[a][b][reg];
+            }
+        }
+}
+
 // ------------------------------------------------------------------ layout conversion
 // reduced [B][rows*n_free] <-> device [B][rows][n_node][4]; free_index[r] = 3*node + dof
 template <typename T, bool PACK>

@@ -43,6 +43,8 @@ struct crb_plan {
     void* d_levels = nullptr;
     void* d_final = nullptr;
     int32_t* d_free_index = nullptr;
+    int32_t* d_col_off = nullptr;  // [2n] reduced state index -> offset in a beam's state record
+    int32_t* d_row_off = nullptr;  // [n]  reduced position index -> offset in a beam's force record
 };
 
 extern "C" int crb_version(void) { return CRB_VERSION; }
@@ -153,6 +155,20 @@ int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::
     HIP_TRY(hipMalloc(&p->d_final, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), p->free_index.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->d_free_index, p->free_index.data(), p->free_index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    {   // offsets of the reduced ordering inside the device layouts (crb_feedback_force)
+        const int n = p->n_free;
+        std::vector<int32_t> col(size_t(2) * n), row(n);
+        for (int r = 0; r < n; ++r) {
+            const int f = p->free_index[r];
+            row[r] = (f / 3) * 4 + (f % 3);
+            col[r] = row[r];
+            col[n + r] = p->n_node * 4 + row[r];
+        }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_col_off), col.size() * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_row_off), row.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(p->d_col_off, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_row_off, row.data(), row.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     if (nd > 1) {
         p->slot_stride = size_t(S);
         p->lv_stride = size_t(lf) * S * PCR_LEVEL_VALS;
@@ -483,6 +499,8 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         (void)hipFree(p->d_levels);
         (void)hipFree(p->d_final);
         (void)hipFree(p->d_free_index);
+        (void)hipFree(p->d_col_off);
+        (void)hipFree(p->d_row_off);
     }
     delete p;
 }
@@ -808,6 +826,35 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     k.rec_out = static_cast<float*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
     if (lean_eligible(p, held)) return launch_lean<float>(p, k, st);
     return launch_beam<float, MODE_STEP>(p, k, st);
+}
+
+extern "C" int crb_feedback_force(const crb_plan* p, const void* xs, const void* gain, const void* ref, void* u, void* stream) {
+    if (int rc = need_device(p, "crb_feedback_force")) return rc;
+    if (!xs || !gain || !u) return fail(CRB_EINVAL, "crb_feedback_force: null pointer");
+    if (p->dtype != CRB_F64) return fail(CRB_EUNSUPPORTED, "crb_feedback_force: fp64 plans only");
+    FeedbackParams f;
+    f.xs = static_cast<const double*>(xs);
+    f.ref = static_cast<const double*>(ref);
+    f.gain = static_cast<const double*>(gain);
+    f.u = static_cast<double*>(u);
+    f.col_off = p->d_col_off;
+    f.row_off = p->d_row_off;
+    f.B = p->B; f.n = p->n_free; f.n2 = 2 * p->n_free;
+    f.x_stride = size_t(2) * p->n_node * 4;
+    f.u_stride = size_t(p->n_node) * 4;
+    // 64 x 64 tiles when they already give every CU >= 3 workgroups, else 32 x 32 (more, smaller groups)
+    const long tiles64 = long((p->B + 63) / 64) * ((p->n_free + 63) / 64);
+    const char* force = std::getenv("CRB_FEEDBACK_TILE");
+    const bool big = force ? (std::atoi(force) == 64) : (tiles64 >= 768);
+    if (big) {
+        const dim3 grid((p->B + 63) / 64, (p->n_free + 63) / 64);
+        hipLaunchKernelGGL((crb_feedback_kernel<64, 64>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), f);
+    } else {
+        const dim3 grid((p->B + 31) / 32, (p->n_free + 31) / 32);
+        hipLaunchKernelGGL((crb_feedback_kernel<32, 32>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), f);
+    }
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
 }
 
 extern "C" int crb_rk4_stage(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage,

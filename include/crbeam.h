@@ -170,6 +170,14 @@ int crb_rhs(const crb_plan* plan, const void* x, const void* u, void* xdot, void
 int crb_step_rk4(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const crb_input_desc* input,
                  double* t_end, void* stream);
 
+/* Feedback force of a whole ensemble, u = K (r - x) (FullStateLinear.compute_input,
+ * control/full_state_linear.py:81; loop of examples/lqr_control.py:95-111), as one fp64-MFMA GEMM with the
+ * gather from the state layout and the scatter into the force layout fused in (fp64 plans only).
+ *   xs   device [B][2][n_node][4]           gain  device [n][2n] row-major, reduced ordering
+ *   ref  device [B][2n] reduced or NULL=0   u     device [B][n_node][4]: free-DOF entries are
+ *                                                  overwritten, the rest must already be zero */
+int crb_feedback_force(const crb_plan* plan, const void* xs, const void* gain, const void* ref, void* u, void* stream);
+
 /* ONE stage of the stage-split RK4 stepper, for inputs that change from stage to stage -- state
  * feedback u = K(r - x) evaluated inside the RHS as examples/lqr_control.py:95-111 does
  * (FullStateLinear.compute_input, control/full_state_linear.py:81).  The caller computes this

@@ -388,3 +388,32 @@ def test_heterogeneous_ensemble_matches_per_beam_oracle(n_e, kind, kw):
         assert rel_err(xd[b], oracle_beam(per_beam[b], **kw).rhs(x[b])) < 1e-10
     with pytest.raises(Exception, match="share n_elem"):
         ensemble([base, nitinol_columns(n_e + 1, kind)], 2, kw)
+
+
+@pytest.mark.parametrize("n_e,B,bcs", [(4, 3, None), (24, 70, None), (128, 130, None),
+                                        (7, 5, ["PINNED", "NONE", "NONE", "FIXED", "NONE", "NONE", "NONE"])])
+def test_fused_mfma_feedback_force_matches_matmul(n_e, B, bcs):
+    """crb_feedback_force (gather + fp64 MFMA GEMM + scatter) against (r - x) @ K^T in torch, with
+    asymmetric random data (an MFMA lane-map mistake cannot hide) and ragged tile edges."""
+    import ctypes as C
+
+    from continuum_robot import _native as nat
+
+    cols = nitinol_columns(n_e, "linear", bcs)
+    ens = ensemble(cols, B, dict(enable_gravity=True))
+    n = ens.n
+    g = torch.Generator(device="cpu").manual_seed(n_e)
+    K = torch.randn((n, 2 * n), generator=g, dtype=torch.float64).to(ens.device)
+    X = torch.randn((B, 2 * n), generator=g, dtype=torch.float64).to(ens.device)
+    R = torch.randn((B, 2 * n), generator=g, dtype=torch.float64).to(ens.device)
+    xs = ens.pack_state(X)
+    for ref in (None, R):
+        u = torch.zeros((B, ens.n_node, 4), dtype=torch.float64, device=ens.device)
+        nat.check(nat.load().crb_feedback_force(ens.plan.h, C.c_void_p(xs.data_ptr()), C.c_void_p(K.data_ptr()),
+                                                C.c_void_p(ref.data_ptr()) if ref is not None else None,
+                                                C.c_void_p(u.data_ptr()), None))
+        torch.cuda.synchronize()
+        want = ((ref if ref is not None else 0) - X) @ K.t()
+        got = ens.unpack_vec(u)
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-13
+        assert float(u[..., 3].abs().max()) == 0.0  # pad lane untouched
