@@ -438,23 +438,25 @@ __host__ __device__ constexpr size_t lean_lds_bytes(int NT, int lognw) {
                         3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
 }
 
+// wave_shr:1 / wave_shl:1 with bound_ctrl: a lane without a source lane reads 0 and no "old" value has
+// to be materialised first (update_dpp(0, ..) costs one extra v_mov per DPP).
 __device__ __forceinline__ double dpp_from_lower(double x) {  // value held by lane-1 (0 into lane 0)
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double dpp_from_higher(double x) {  // value held by lane+1 (0 into lane 63)
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float dpp_from_lower(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float dpp_from_higher(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130, 0xf, 0xf, true));
 }
 // Value of lane-D / lane+D of the same wave.  D <= DPP_MAX: chained DPP wave shifts (VALU, no
 // LDS round trip; lanes shifted in from outside the wave read 0).  Larger D: ds_bpermute; a lane
