@@ -80,6 +80,12 @@ CRB_HD void elem_force_linear(const T* c, const T ql[3], const T qr[3], T fl[3],
 // the regrouped polynomial equals the shipped one identically.  f5 = -f3 term by term in the
 // reference.  corrected == false keeps the shipped f1 (it lacks the
 // -EA/L*u2 coupling); corrected == true uses f1 = -f2.
+// base + c * ww, dropped at compile time when the literal remainder c is exactly 0
+template <typename T>
+CRB_HD T plus_remainder(T base, double c, T ww) {
+    return c == 0.0 ? base : base + T(c) * ww;
+}
+
 template <typename T>
 CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
     const T L = c[0], A = c[1], D = c[2], iL2 = c[3], tenth_iL3 = c[4];
@@ -98,16 +104,16 @@ CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool 
     const T f1 = corrected ? -f2 : A * iL2 * (L * u1 - P - (u2 + dw) * T0);
 
     // ---- f3 = -f5 (segments.py:279-314, 386-421)
-    const T Qa = T(3.8571428571413) * dw2 + T(2.0 * 3.8571428571413 - 7.7142857142826) * ww;
-    const T Qb = T(3.857142857143) * dw2 + T(2.0 * 3.857142857143 - 7.71428571428601) * ww;
-    const T Cw = dw * (T(10.2857142857147) * dw2 + T(3.0 * 10.2857142857147 - 30.857142857144) * ww);
+    const T Qa = plus_remainder<T>(T(3.8571428571413) * dw2, 2.0 * 3.8571428571413 - 7.7142857142826, ww);
+    const T Qb = plus_remainder<T>(T(3.857142857143) * dw2, 2.0 * 3.857142857143 - 7.71428571428601, ww);
+    const T Cw = dw * plus_remainder<T>(T(10.2857142857147) * dw2, 3.0 * 10.2857142857147 - 30.857142857144, ww);
     const T P3 = T(0.0357142857143344) * (a2 * a + b2 * b) - T(0.107142857143003) * ab * (a + b) +
                  T(1.28571428571433) * (a2 + b2) * dw + Ldu * (a + b) - a * Qa - b * Qb - T(12.0) * Ldu * dw + Cw;
     const T f3 = tenth_iL3 * (A * P3 + D * (T(120.0) * dw - T(60.0) * (a + b)));
 
     // ---- f4 (segments.py:335-365)
-    const T Q4 = T(0.128571428571433) * dw2 + T(2.0 * 0.128571428571433 - 0.257142857142867) * ww;
-    const T C4 = dw * (T(0.128571428571377) * dw2 + T(3.0 * 0.128571428571377 - 0.38571428571413) * ww);
+    const T Q4 = plus_remainder<T>(T(0.128571428571433) * dw2, 2.0 * 0.128571428571433 - 0.257142857142867, ww);
+    const T C4 = dw * plus_remainder<T>(T(0.128571428571377) * dw2, 3.0 * 0.128571428571377 - 0.38571428571413, ww);
     const T P4 = T(0.0285714285714391) * a2 * a - T(0.0107142857142861) * a2 * b + T(0.0107142857142719) * a2 * dw +
                  T(0.00714285714286444) * a * b2 - T(0.0214285714286007) * ab * dw - T(0.133333333333333) * a * Ldu +
                  a * Q4 - T(0.00357142857143344) * b2 * b - T(0.0107142857142719) * b2 * dw +
@@ -115,8 +121,8 @@ CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool 
     const T f4 = iL2 * (A * P4 + D * (T(4.0) * a + T(2.0) * b - T(6.0) * dw));
 
     // ---- f6 (segments.py:442-472)
-    const T Q6 = T(0.128571428571428) * dw2 + T(2.0 * 0.128571428571428 - 0.257142857142856) * ww;
-    const T C6 = dw * (T(0.128571428571433) * dw2 + T(3.0 * 0.128571428571433 - 0.3857142857143) * ww);
+    const T Q6 = plus_remainder<T>(T(0.128571428571428) * dw2, 2.0 * 0.128571428571428 - 0.257142857142856, ww);
+    const T C6 = dw * plus_remainder<T>(T(0.128571428571433) * dw2, 3.0 * 0.128571428571433 - 0.3857142857143, ww);
     const T P6 = -T(0.00357142857143344) * a2 * a + T(0.00714285714286356) * a2 * b - T(0.0107142857143003) * a2 * dw -
                  T(0.0107142857142932) * a * b2 - T(0.021428571428558) * ab * dw + T(0.0333333333333333) * a * Ldu +
                  T(0.0285714285714271) * b2 * b + T(0.0107142857142932) * b2 * dw - T(0.133333333333333) * b * Ldu +

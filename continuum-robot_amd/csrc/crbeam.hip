@@ -609,18 +609,29 @@ KParams<T> base_params(const crb_plan* p) {
     return k;
 }
 
+// dynamic LDS above 64 KiB must be opted into per kernel (the CU has 160 KiB)
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+    return CRB_OK;
+}
+
 template <typename T, int MODE, int LV, bool LEAN>
 int launch_beam_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);
     const size_t smem = lds_bytes<T>(p->NT);
     // register budget: <=256-thread groups run 2 groups per CU (2 waves/SIMD, 256 VGPRs) so that the
     // solve multipliers stay in registers; 1024-thread groups get what their size allows
-    if (p->NT <= 256)
+    if (p->NT <= 256) {
         hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 256, 2, LEAN>), grid, block, smem, st, k);
-    else if (p->NT <= 512)
+    } else if (p->NT <= 512) {
+        if (int rc = allow_lds(crb_beam_kernel<T, MODE, LV, 512, 2, LEAN>, smem)) return rc;
         hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 512, 2, LEAN>), grid, block, smem, st, k);
-    else
+    } else {
+        if (int rc = allow_lds(crb_beam_kernel<T, MODE, LV, 1024, 4, LEAN>, smem)) return rc;
         hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 1024, 4, LEAN>), grid, block, smem, st, k);
+    }
     HIP_TRY(hipGetLastError());
     return CRB_OK;
 }
@@ -653,7 +664,9 @@ int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 template <typename T, int LV, int LOGNW>
 int launch_lean_one(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     const dim3 grid(p->B), block(64 << LOGNW);
-    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW>), grid, block, lean_lds_bytes<T>(64 << LOGNW, LOGNW), st, k);
+    const size_t smem = lean_lds_bytes<T>(64 << LOGNW, LOGNW);
+    if (int rc = allow_lds(crb_step_lean_kernel<T, LV, LOGNW>, smem)) return rc;
+    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW>), grid, block, smem, st, k);
     HIP_TRY(hipGetLastError());
     return CRB_OK;
 }

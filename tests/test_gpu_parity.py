@@ -163,12 +163,27 @@ def test_held_force_and_pack_roundtrip():
     assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-10
 
 
-@pytest.mark.parametrize("n_e,B", [(1, 1), (2, 70), (10, 13), (63, 5), (65, 3), (130, 2), (300, 2)])
+@pytest.mark.parametrize("n_e,B", [(1, 1), (2, 70), (10, 13), (63, 5), (65, 3), (130, 2), (300, 2), (600, 2), (1024, 1)])
 def test_ragged_sizes_and_partial_groups(n_e, B):
     """Beam sizes around the wavefront/workgroup boundaries, batch sizes that leave a group partly empty."""
     kinds = ["nonlinear" if i % 2 else "linear" for i in range(n_e)]
     cols = nitinol_columns(n_e, kinds)
     kw = dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True, gravity=[1.0, -9.81, 0.0])
+    ob = oracle_beam(cols, **kw)
+    amps = 0.05 * (1.0 + np.arange(B))
+    ens = ensemble(cols, B, kw)
+    ens.step(120, 2e-5, impulse_amp=amps)
+    ref, _ = ob.rk4_impulse_batch(np.zeros((B, 2 * ob.n)), 2e-5, 120, amps)
+    assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
+
+
+@pytest.mark.parametrize("n_e,B", [(33, 3), (64, 2), (100, 3), (128, 2), (200, 2), (300, 2), (512, 2)])
+def test_lean_stepper_sizes(n_e, B):
+    """The lean fused stepper (no gravity) for every waves-per-beam count it is built for, incl. beams
+    that leave padding threads and the > 64 KiB LDS case."""
+    kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)]
+    cols = nitinol_columns(n_e, kinds)
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
     ob = oracle_beam(cols, **kw)
     amps = 0.05 * (1.0 + np.arange(B))
     ens = ensemble(cols, B, kw)
