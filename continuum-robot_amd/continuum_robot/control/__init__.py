@@ -1,5 +1,6 @@
-"""Control layer (stays Python and calls the stepper).  Reference: src/continuum_robot/control/__init__.py:1-4."""
-from .linear_quadratic_regulator import LinearQuadraticRegulator
+"""Control layer of the drop-in package: stays in Python and drives the GPU stepper
+(``BeamEnsemble.step_feedback`` takes the gain computed here)."""
 from .full_state_linear import FullStateLinear
+from .linear_quadratic_regulator import LinearQuadraticRegulator
 
-__all__ = ["LinearQuadraticRegulator", "FullStateLinear"]
+__all__ = ["FullStateLinear", "LinearQuadraticRegulator"]
