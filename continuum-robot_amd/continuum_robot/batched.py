@@ -211,6 +211,47 @@ class BeamEnsemble:
         self.time = t_end.value
         return (self.time, samples) if record is not None else self.time
 
+    def solve_rk45(self, t_end: float, rtol: float = 1e-3, atol: float = 1e-6, impulse_amp=None,
+                   impulse_duration: float = 0.01, impulse_index: int = -2, held_force=None,
+                   first_step=None, t0: Optional[float] = None, max_steps: int = 0):
+        """Integrate every beam from the current clock to ``t_end`` with adaptive Dormand-Prince 5(4),
+        per-beam step control, in ONE kernel launch -- the algorithm (and defaults) of
+        ``scipy.integrate.solve_ivp(method="RK45")`` that the reference's tests call
+        (tests/test_dynamic_beam.py:218-220).  Returns a dict of per-beam statistics:
+        accepted / rejected steps, nfev, status (0 = reached t_end), next_step."""
+        if t0 is not None:
+            self.time = float(t0)
+        desc = nat.InputDesc()
+        desc.kind = nat.CRB_INPUT_NONE
+        keep = []
+        if impulse_amp is not None:
+            amp = self._dev(impulse_amp, (self.n_beams,))
+            idx = impulse_index if impulse_index >= 0 else self.n + impulse_index
+            if not 0 <= idx < self.n:
+                raise IndexError("impulse_index out of range")
+            full = int(self.free_index[idx])
+            desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, full // 3, full % 3
+            desc.duration = float(impulse_duration)
+            desc.amp = amp.data_ptr()
+            keep.append(amp)
+        if held_force is not None:
+            held = self.pack_vec(held_force)
+            desc.f_held = held.data_ptr()
+            keep.append(held)
+        h = torch.zeros((self.n_beams,), dtype=torch.float64, device=self.device)
+        if first_step is not None:
+            h += torch.as_tensor(first_step, dtype=torch.float64, device=self.device)
+        stats = torch.zeros((self.n_beams, 4), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_solve_rk45(self.plan.h, self._ptr(self.state), self.time, float(t_end), float(rtol),
+                                               float(atol), C.byref(desc), self._ptr(h), self._ptr(stats), int(max_steps),
+                                               self._stream()))
+        self._keep = keep + [h, stats]
+        self.time = float(t_end)
+        st = stats.cpu().numpy()
+        return {"accepted": st[:, 0], "rejected": st[:, 1], "nfev": st[:, 2], "status": st[:, 3],
+                "next_step": h.cpu().numpy()}
+
     def step_feedback(self, n_steps: int, dt: float, gain, reference=None, impulse_amp=None,
                       impulse_duration: float = 0.01, impulse_index: int = -2, t0: Optional[float] = None) -> float:
         """Closed-loop rollout: RK4 with the state feedback u = K (r - x) evaluated inside the RHS at

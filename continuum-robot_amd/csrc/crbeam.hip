@@ -841,6 +841,75 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     return launch_beam<float, MODE_STEP>(p, k, st);
 }
 
+namespace {
+template <typename T, int LV>
+int launch_rk45_lv(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hipStream_t st) {
+    const dim3 grid(p->B), block(p->NT);
+    const size_t smem = rk45_lds_bytes<T>(p->NT);
+    if (p->NT <= 256) {
+        if (int rc = allow_lds(crb_rk45_kernel<T, LV, 256, 1>, smem)) return rc;
+        hipLaunchKernelGGL((crb_rk45_kernel<T, LV, 256, 1>), grid, block, smem, st, k, q);
+    } else {
+        if (int rc = allow_lds(crb_rk45_kernel<T, LV, 1024, 1>, smem)) return rc;
+        hipLaunchKernelGGL((crb_rk45_kernel<T, LV, 1024, 1>), grid, block, smem, st, k, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}
+template <typename T>
+int launch_rk45(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hipStream_t st) {
+    switch (p->levels) {
+        case 0: return launch_rk45_lv<T, 0>(p, k, q, st);
+        case 1: return launch_rk45_lv<T, 1>(p, k, q, st);
+        case 2: return launch_rk45_lv<T, 2>(p, k, q, st);
+        case 3: return launch_rk45_lv<T, 3>(p, k, q, st);
+        case 4: return launch_rk45_lv<T, 4>(p, k, q, st);
+        case 5: return launch_rk45_lv<T, 5>(p, k, q, st);
+        case 6: return launch_rk45_lv<T, 6>(p, k, q, st);
+        default: return fail(CRB_EUNSUPPORTED, "crb_solve_rk45: unsupported number of cyclic-reduction levels");
+    }
+}
+}  // namespace
+
+extern "C" int crb_solve_rk45(const crb_plan* p, void* x, double t0, double t_end, double rtol, double atol,
+                              const crb_input_desc* in, void* h, void* stats, int max_steps, void* stream) {
+    if (int rc = need_device(p, "crb_solve_rk45")) return rc;
+    if (!x) return fail(CRB_EINVAL, "crb_solve_rk45: null state");
+    if (!(t_end > t0)) return fail(CRB_EINVAL, "crb_solve_rk45: t_end must be greater than t0");
+    if (!(rtol > 0) || !(atol >= 0)) return fail(CRB_EINVAL, "crb_solve_rk45: tolerances must be positive");
+    if (p->G != 1) return fail(CRB_EUNSUPPORTED, "crb_solve_rk45: beams with fewer than 33 thread-carried nodes are not supported");
+    if (rk45_lds_bytes<double>(p->NT) > 160 * 1024)
+        return fail(CRB_EUNSUPPORTED, "crb_solve_rk45: beam too long for the LDS-resident stage storage");
+    int imp_slot = -1, imp_dof = 0;
+    double duration = 0.0;
+    const void* amp = nullptr;
+    const void* held = nullptr;
+    if (in) {
+        held = in->f_held;
+        if (in->kind == CRB_INPUT_IMPULSE) {
+            if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp ||
+                p->full2red[3 * in->node + in->dof] < 0)
+                return fail(CRB_EINVAL, "crb_solve_rk45: bad impulse description");
+            imp_slot = in->node - p->off; imp_dof = in->dof; duration = in->duration; amp = in->amp;
+        }
+    }
+    Rk45Params q;
+    q.t0 = t0; q.t_end = t_end; q.rtol = rtol; q.atol = atol;
+    q.h_io = static_cast<double*>(h); q.stats = static_cast<int32_t*>(stats);
+    q.n_state = 2 * p->n_free; q.max_steps = max_steps > 0 ? max_steps : 100000000;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->dtype == CRB_F64) {
+        KParams<double> k = base_params<double>(p);
+        k.x = static_cast<double*>(x); k.u_held = static_cast<const double*>(held); k.amp = static_cast<const double*>(amp);
+        k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+        return launch_rk45<double>(p, k, q, st);
+    }
+    KParams<float> k = base_params<float>(p);
+    k.x = static_cast<float*>(x); k.u_held = static_cast<const float*>(held); k.amp = static_cast<const float*>(amp);
+    k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+    return launch_rk45<float>(p, k, q, st);
+}
+
 extern "C" int crb_feedback_force(const crb_plan* p, const void* xs, const void* gain, const void* ref, void* u, void* stream) {
     if (int rc = need_device(p, "crb_feedback_force")) return rc;
     if (!xs || !gain || !u) return fail(CRB_EINVAL, "crb_feedback_force: null pointer");

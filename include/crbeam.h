@@ -170,6 +170,16 @@ int crb_rhs(const crb_plan* plan, const void* x, const void* u, void* xdot, void
 int crb_step_rk4(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const crb_input_desc* input,
                  double* t_end, void* stream);
 
+/* Adaptive integration t0 -> t_end of every beam with embedded Dormand-Prince 5(4) and per-beam step-size
+ * control, one launch: the algorithm of scipy.integrate.solve_ivp(method="RK45"), which the reference's
+ * tests hand their RHS to (tests/test_dynamic_beam.py:218-220, test_functional_composition.py:539-546).
+ *   h    device [B] fp64: in  first step per beam (<= 0: scipy's select_initial_step), out next step
+ *   stats device [B][4] int32: accepted steps, rejected steps, RHS evaluations, status (0 ok / 1 step
+ *        too small or max_steps exceeded).  h and stats may be NULL.  Plans with one beam per workgroup
+ *        (n_slots >= 33) only. */
+int crb_solve_rk45(const crb_plan* plan, void* x, double t0, double t_end, double rtol, double atol,
+                   const crb_input_desc* input, void* h, void* stats, int max_steps, void* stream);
+
 /* Feedback force of a whole ensemble, u = K (r - x) (FullStateLinear.compute_input,
  * control/full_state_linear.py:81; loop of examples/lqr_control.py:95-111), as one fp64-MFMA GEMM with the
  * gather from the state layout and the scatter into the force layout fused in (fp64 plans only).

@@ -455,8 +455,56 @@ def g6_lqr_loop():
     np.savez_compressed(os.path.join(HERE, "g6_lqr_loop.npz"), **out)
 
 
+# --------------------------------------------------------------------------- G7
+def g7_rk45():
+    """scipy.integrate.solve_ivp(method="RK45") over the reference RHS, the call pattern of the reference's
+    own tests (tests/test_dynamic_beam.py:218-220: default rtol/atol; test_functional_composition.py:539-546:
+    rtol=1e-6), with the examples' tip impulse.  Pins terminal state, accepted steps and nfev."""
+    from scipy.integrate import solve_ivp
+
+    out = {}
+    jobs = [
+        ("lin40_grav", nitinol(40, "linear"), dict(enable_gravity_effects=True), 0.1, 0.002, 0.004, 1e-3, 1e-6),
+        ("nl64_drag", nitinol(64, "nonlinear"), dict(fluid_density=1000.0, enable_fluid_effects=True), 0.1, 0.001, 0.002,
+         1e-6, 1e-9),
+    ]
+    for name, df, kw, amp, duration, t_end, rtol, atol in jobs:
+        t_start = time.time()
+        out.update(fp_arrays(name, kw))
+        path = write_csv(df)
+        try:
+            beam = DynamicEulerBernoulliBeam(path, force_params=ForceParams(**kw))
+        finally:
+            os.unlink(path)
+        out.update(df_arrays(name, beam.params))
+        beam.create_system_func()
+        beam.create_input_func()
+        dyn = beam.get_dynamic_system()
+        n = beam.beam_model.M.shape[0]
+
+        def u_of_t(t, n=n, amp=amp, duration=duration):
+            u = np.zeros(n)
+            if t < duration:
+                u[-2] = amp
+            return u
+
+        sol = solve_ivp(lambda t, x: dyn(t, x, u_of_t(t)), (0.0, t_end), np.zeros(2 * n), method="RK45", rtol=rtol,
+                        atol=atol)
+        assert sol.success
+        for k, v in (("amp", amp), ("duration", duration), ("t_end", t_end), ("rtol", rtol), ("atol", atol)):
+            out[f"{name}/{k}"] = np.float64(v)
+        out[f"{name}/x_final"] = sol.y[:, -1]
+        out[f"{name}/nfev"] = np.int32(sol.nfev)
+        out[f"{name}/accepted"] = np.int32(len(sol.t) - 1)
+        out[f"{name}/t_steps"] = sol.t
+        print(f"G7 {name}: {len(sol.t) - 1} steps, nfev {sol.nfev}, tip w = {sol.y[n - 2, -1]!r} ({time.time() - t_start:.0f} s)")
+    np.savez_compressed(os.path.join(HERE, "g7_rk45.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7"]
+    if "g7" in which:
+        g7_rk45()
     if "g6" in which:
         g6_lqr_loop()
     if "g1" in which:

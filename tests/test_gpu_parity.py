@@ -432,3 +432,47 @@ def test_fused_mfma_feedback_force_matches_matmul(n_e, B, bcs):
         got = ens.unpack_vec(u)
         assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-13
         assert float(u[..., 3].abs().max()) == 0.0  # pad lane untouched
+
+
+@pytest.mark.parametrize("name", ["lin40_grav", "nl64_drag"])
+def test_adaptive_rk45_matches_scipy_on_the_reference_rhs(golden, name):
+    """f-2: crb_solve_rk45 (Dormand-Prince 5(4), per-beam step control, one launch) against
+    scipy.integrate.solve_ivp(method="RK45") run over the REFERENCE RHS (tests/golden/make_golden.py:g7_rk45):
+    same accepted-step count, same number of RHS evaluations, same terminal state."""
+    z = golden["g7_rk45"]
+    B = 3
+    ens = ensemble(beam_columns(z, name), B, force_kwargs(z, name))
+    st = ens.solve_rk45(float(z[f"{name}/t_end"]), rtol=float(z[f"{name}/rtol"]), atol=float(z[f"{name}/atol"]),
+                        impulse_amp=np.full(B, float(z[f"{name}/amp"])), impulse_duration=float(z[f"{name}/duration"]))
+    assert np.all(st["status"] == 0)
+    assert np.all(st["accepted"] == int(z[f"{name}/accepted"])), (st["accepted"], int(z[f"{name}/accepted"]))
+    assert np.all(st["nfev"] == int(z[f"{name}/nfev"]))
+    got = ens.unpack_state().cpu().numpy()
+    assert rel_err(got[0], z[f"{name}/x_final"]) < 1e-8
+    assert np.array_equal(got[0], got[2])
+
+
+def test_adaptive_rk45_per_beam_step_control_matches_scipy_over_oracle():
+    """Different impulse amplitudes -> different step sequences per beam; each against scipy over the oracle RHS."""
+    from scipy.integrate import solve_ivp
+
+    cols = nitinol_columns(48, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True)
+    ob = oracle_beam(cols, **kw)
+    n, B = ob.n, 4
+    amps = np.array([0.02, 0.1, 0.5, 2.0])
+    dur, t_end, rtol, atol = 5e-4, 1.2e-3, 1e-5, 1e-8
+    ens = ensemble(cols, B, kw)
+    st = ens.solve_rk45(t_end, rtol=rtol, atol=atol, impulse_amp=amps, impulse_duration=dur)
+    got = ens.unpack_state().cpu().numpy()
+    assert len(set(st["accepted"].tolist())) > 1  # the beams really took different numbers of steps
+    for b in range(B):
+        def fun(t, x, b=b):
+            u = np.zeros(n)
+            if t < dur:
+                u[-2] = amps[b]
+            return ob.rhs(x, u)
+
+        sol = solve_ivp(fun, (0.0, t_end), np.zeros(2 * n), method="RK45", rtol=rtol, atol=atol)
+        assert st["accepted"][b] == len(sol.t) - 1 and st["nfev"][b] == sol.nfev, (b, st["accepted"][b], len(sol.t) - 1)
+        assert rel_err(got[b], sol.y[:, -1]) < 1e-8

@@ -150,3 +150,26 @@ def test_g6_lqr_closed_loop(golden, name):
     x = ob.rk4_feedback(np.zeros(2 * ob.n), float(z[f"{name}/dt"]), int(z[f"{name}/steps"]), z[f"{name}/gain"],
                         amp=float(z[f"{name}/amp"]))
     assert rel_err(x, z[f"{name}/x_final"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["lin40_grav", "nl64_drag"])
+def test_g7_scipy_rk45_over_oracle_rhs(golden, name):
+    """scipy's RK45 over the oracle RHS takes the same steps as over the reference RHS."""
+    from scipy.integrate import solve_ivp
+
+    z = golden["g7_rk45"]
+    ob = oracle_beam(beam_columns(z, name), **force_kwargs(z, name))
+    n = ob.n
+    amp, dur = float(z[f"{name}/amp"]), float(z[f"{name}/duration"])
+
+    def fun(t, x):
+        u = np.zeros(n)
+        if t < dur:
+            u[-2] = amp
+        return ob.rhs(x, u)
+
+    sol = solve_ivp(fun, (0.0, float(z[f"{name}/t_end"])), np.zeros(2 * n), method="RK45", rtol=float(z[f"{name}/rtol"]),
+                    atol=float(z[f"{name}/atol"]))
+    assert sol.nfev == int(z[f"{name}/nfev"]) and len(sol.t) - 1 == int(z[f"{name}/accepted"])
+    assert np.allclose(sol.t, z[f"{name}/t_steps"], rtol=1e-9, atol=0)
+    assert rel_err(sol.y[:, -1], z[f"{name}/x_final"]) < 1e-8
