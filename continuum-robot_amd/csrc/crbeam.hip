@@ -52,23 +52,6 @@ extern "C" const char* crb_last_error(void) { return g_err.c_str(); }
 
 namespace {
 
-struct HostTables {
-    std::vector<SlotConst<double>> slot;
-};
-
-template <typename T>
-SlotConst<T> convert_slot(const SlotConst<double>& s, int kind, double L, double E, double I, double A) {
-    SlotConst<T> o;
-    std::memset(&o, 0, sizeof(o));
-    elem_coef_build<T>(o.elem, kind, L, E, I, A);
-    o.drag = T(s.drag);
-    o.half_mass = T(s.half_mass);
-    for (int c = 0; c < 3; ++c) o.mask[c] = T(s.mask[c]);
-    o.pad0 = T(0);
-    o.grav = s.grav;
-    return o;
-}
-
 // ---- device-side assembly (crb_assemble_kernel) -------------------------------------------------
 template <typename X>
 struct DevBuf {
