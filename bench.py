@@ -66,7 +66,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--launch-steps", type=int, default=0, help="RK4 steps fused per launch (0 = all of --steps)")
+    ap.add_argument("--launch-steps", type=int, default=100,
+                    help="RK4 steps fused per launch (0 = all of --steps); warmup uses launches of the same size, so "
+                         "every stepper launch of a run is identical and rocprof's per-kernel average is the launch time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hetero", action="store_true",
                     help="heterogeneous variant (SURVEY 8(d)): per-beam E, rho, r scaled by U(0.9, 1.1), seed 4321")
@@ -185,8 +187,11 @@ def main():
     # ---- warmup (untimed), then restore the initial state so the timed K steps are the
     # parity-checked trajectory (the shipped nonlinear element is only stable to ~1000 steps)
     reset()
-    if args.warmup > 0:
-        advance(args.warmup)
+    w_done = 0
+    while w_done < args.warmup:
+        k = min(per_launch, args.warmup - w_done)
+        advance(k)
+        w_done += k
     reset()
     torch.cuda.synchronize()
     if dist:
