@@ -4,13 +4,13 @@ Reference: src/continuum_robot/models/dynamic_beam_model.py:16-364 -- same const
 (CSV + ForceParams), attributes and closure API (create_system_func / create_input_func /
 get_system_func / get_dynamic_system), same validation messages.
 
-Where the work runs.  The closures keep the reference's functional-composition contract: the
-force function is an arbitrary Python callable (registry aggregate or user supplied) evaluated
-per call on the host; the structural part -- k(q) and the mass solve -- is one launch of the RHS
-kernel (crb_rhs) with the summed generalised force as its input vector, so
-``system(x) + input(x, u, t)`` costs one kernel instead of the reference's Python element loop and
-three sparse products.  Rollouts of many beams should use ``to_ensemble()`` /
-``continuum_robot.batched.BeamEnsemble``, where drag and gravity are fused into the stepper.
+Where the work runs.  ``system(x)`` is one launch of the RHS kernel (crb_rhs): k(q), the mass solve
+and -- for the registry-based default -- the auto-registered drag and gravity terms all run fused on
+the GPU (the registry is re-read on every call, so toggling ``force.enabled`` or changing the gravity
+vector still takes effect immediately).  Only what cannot be lowered is evaluated on the host, as the
+functional-composition API demands: a user-supplied ``forces_func`` and user-registered force objects
+are arbitrary Python callables; their sum enters the kernel as its input vector.  Rollouts of many
+beams should use ``to_ensemble()`` / ``continuum_robot.batched.BeamEnsemble``.
 """
 import pathlib
 from typing import Callable, Dict, Union
@@ -89,14 +89,18 @@ class DynamicEulerBernoulliBeam:
 
     def _auto_register_forces(self) -> None:
         fp = self.force_params
+        self._auto_drag = self._auto_gravity = None
+        self._fused = {}
         if fp.enable_fluid_effects:
-            self.force_registry.register(FluidDragForce(
+            self._auto_drag = FluidDragForce(
                 fluid_data=self.params[["wetted_area", "drag_coef"]], state_mapping=self.state_to_node_param,
-                fluid_density=fp.fluid_density, enabled=True))
+                fluid_density=fp.fluid_density, enabled=True)
+            self.force_registry.register(self._auto_drag)
         if fp.enable_gravity_effects:
-            self.force_registry.register(GravityForce(
+            self._auto_gravity = GravityForce(
                 beam_params=self.params[["density", "cross_area", "length"]],
-                gravity_vector=fp.get_gravity_vector(), enabled=True))
+                gravity_vector=fp.get_gravity_vector(), enabled=True)
+            self.force_registry.register(self._auto_gravity)
 
     # ------------------------------------------------------------------ attributes
     @property
@@ -128,6 +132,43 @@ class DynamicEulerBernoulliBeam:
         return self.node_param_to_state.copy()
 
     # ------------------------------------------------------------------ device path
+    def _fused_ensemble(self, drag_on: bool, gravity):
+        """One-beam GPU ensemble with the given built-in force terms fused into the RHS kernel."""
+        key = (bool(drag_on), None if gravity is None else tuple(float(g) for g in gravity))
+        if key not in self._fused:
+            from ..batched import BeamEnsemble
+
+            fp = ForceParams(fluid_density=self.force_params.fluid_density if drag_on else 0.0,
+                             enable_fluid_effects=bool(drag_on),
+                             gravity_vector=list(key[1]) if key[1] is not None else [0.0, -9.81, 0.0],
+                             enable_gravity_effects=key[1] is not None)
+            self._fused[key] = BeamEnsemble(self.params, 1, force_params=fp)
+        return self._fused[key]
+
+    def _registry_rhs(self, x: np.ndarray) -> np.ndarray:
+        """system(x) of the registry-based default: enabled auto-registered drag / gravity are lowered to
+        the kernel's fused force terms, every other registered force is a Python callable summed on the
+        host (force time argument 0.0, reference :265)."""
+        drag_on, gravity, extra = False, None, None
+        for force in self.force_registry.get_registered_forces():
+            if not force.is_enabled():
+                continue
+            if force is self._auto_drag and force.fluid_coefficients is not None:
+                drag_on = True
+            elif force is self._auto_gravity:
+                gravity = force.get_gravity_vector()
+            else:
+                part = np.asarray(force.compute_forces(x, 0.0), dtype=np.float64)
+                extra = part.copy() if extra is None else extra + part
+        ens = self._fused_ensemble(drag_on, gravity)
+        n = ens.n
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim != 1 or x.shape[0] != 2 * n:
+            raise ValueError(f"State vector length {x.shape} must be {2 * n}")
+        if extra is not None and extra.shape != (n,):
+            raise ValueError(f"dimension mismatch: force vector of length {extra.shape} for {n} position DOFs")
+        return ens.rhs(x.reshape(1, -1), None if extra is None else extra.reshape(1, -1)).cpu().numpy()[0]
+
     def _structural_rhs(self, x: np.ndarray, generalized_force: np.ndarray) -> np.ndarray:
         """[v ; Minv(-k(q) + force)] by one launch of the RHS kernel (one beam)."""
         ens = self.beam_model._device_ensemble()
@@ -151,10 +192,11 @@ class DynamicEulerBernoulliBeam:
         """system(x) = [v ; Minv(-k(q) + forces_func(x, 0.0))]; forces default to the registry.
         (The force time argument is always 0.0, as in the reference, :265.)"""
         if forces_func is None:
-            forces_func = self.force_registry.create_aggregated_function()
+            self.system_func = self._registry_rhs  # built-in forces fused on the GPU
+            return
 
         def system(x):
-            additional = forces_func(x, 0.0)
+            additional = forces_func(x, 0.0)  # arbitrary user callable: host by construction
             return self._structural_rhs(x, np.asarray(additional, dtype=np.float64))
 
         self.system_func = system

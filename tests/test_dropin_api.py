@@ -494,3 +494,45 @@ def test_to_ensemble_is_the_fused_path(beam_files):
     fused = ens.rhs(X, U).cpu().numpy()
     for b in range(3):  # closure path (host force callables + RHS kernel) == fused kernel path
         assert rel_err(beam.get_dynamic_system()(0.0, X[b], U[b]), fused[b]) < 1e-12
+
+
+@gpu
+def test_fused_registry_path_equals_host_composed_path_and_follows_runtime_changes(beam_files):
+    """create_system_func() lowers the auto-registered drag / gravity to the kernel's fused terms; handing
+    the registry's own aggregate in as an external callable evaluates the same forces through their numpy
+    methods.  Both must agree, also after toggling `.enabled` and changing the gravity vector at run time
+    (force_registry.py:66-67 semantics, test_advanced_composition.py:368-398)."""
+    from continuum_robot.models.dynamic_beam_model import DynamicEulerBernoulliBeam
+    from continuum_robot.models.force_params import ForceParams
+
+    fp = ForceParams(fluid_density=1000.0, enable_fluid_effects=True, enable_gravity_effects=True)
+    fused = DynamicEulerBernoulliBeam(beam_files[1], force_params=fp)
+    hosted = DynamicEulerBernoulliBeam(beam_files[1], force_params=fp)
+    fused.create_system_func()
+    hosted.create_system_func(hosted.force_registry.create_aggregated_function())
+    n = fused.beam_model.M.shape[0]
+    x = np.random.default_rng(5).normal(0, 1e-2, 2 * n)
+    x[n:] *= 30.0
+    drag_f, grav_f = fused.force_registry.get_registered_forces()
+    drag_h, grav_h = hosted.force_registry.get_registered_forces()
+
+    def same():
+        a, b = fused.get_system_func()(x), hosted.get_system_func()(x)
+        assert rel_err(a, b) < 1e-12
+        return a
+
+    base = same()
+    grav_f.enabled = grav_h.enabled = False
+    no_grav = same()
+    assert not np.allclose(no_grav, base)
+    drag_f.enabled = drag_h.enabled = False
+    bare = same()
+    assert not np.allclose(bare, no_grav)
+    grav_f.enabled = grav_h.enabled = True
+    for g in (grav_f, grav_h):
+        g.set_gravity_vector([2.0, -1.0, 0.0])
+    tilted = same()
+    assert not np.allclose(tilted, bare)
+    fused.force_registry.register(MockForce(n, 0.5))   # a user force joins the fused built-ins
+    hosted.force_registry.register(MockForce(n, 0.5))
+    same()
