@@ -34,7 +34,7 @@ def gather_terminal_states(local: torch.Tensor, group=None) -> torch.Tensor:
     One collective per rollout: with nccl this is a single RCCL all-gather (direct over the xGMI
     mesh); message = local.numel() * itemsize bytes per rank.
     """
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     local = local.contiguous()
