@@ -198,6 +198,7 @@ def main():
     # code objects, which 100 steps (4 ms) do not cover (observed once: a first run at half speed)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.3:
+        reset()
         advance(per_launch)
         torch.cuda.synchronize()
     reset()
