@@ -210,7 +210,7 @@ def main():
     if dist:
         # warm the collective path too (RCCL builds its communicator / channels lazily on first use:
         # tens of ms that do not belong to the timed steps)
-        gather_terminal_states(ens.state)
+        gather_terminal_states(ens.unpack_state())
         warm = torch.zeros(1, dtype=torch.float64, device=ens.device)
         dist.all_reduce(warm, op=dist.ReduceOp.MAX)
         dist.barrier()
@@ -231,7 +231,9 @@ def main():
         e1.record()
         events.append((e0, e1, k))
         done += k
-    gathered = gather_terminal_states(ens.state)  # the one exchange (RCCL all-gather); no-op at N = 1
+    # the one exchange: RCCL all-gather of the terminal states in the reference's reduced ordering
+    # ([B, 2n], no padding lanes: 50 MB per rank for config 3); no-op at N = 1
+    gathered = gather_terminal_states(ens.unpack_state())
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -279,7 +281,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["label"] + (" [heterogeneous: per-beam coefficients]" if args.hetero else ""), "beams_per_gpu": B, "beams_total": B_total, "elements": ne,
                        "dt": dt, "steps_per_launch": min(per_launch, args.steps), "parallelism": f"beam-shard x{world}",
-                       "collective": "all_gather_into_tensor(terminal states)" if world > 1 else "none",
+                       "collective": "all_gather_into_tensor(terminal states [B,2n])" if world > 1 else "none",
                        "plan_ms": plan_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
