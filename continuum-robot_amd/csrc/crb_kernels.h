@@ -748,8 +748,8 @@ __device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
 }
 
 template <typename T, int LV, int LOGNW>
-// 2 waves/SIMD: 256 VGPRs hold the multipliers (forcing fp32 to 4 waves/SIMD spills: 3x slower, measured)
-__global__ void __launch_bounds__(64 << LOGNW, 2) crb_step_lean_kernel(const KParams<T> p) {
+// fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: 3 waves/SIMD (168 VGPRs; 4 waves/SIMD spills)
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_step_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N, RV = LeanRec<T>::V;
     constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
