@@ -112,6 +112,8 @@ def load():
     L.crb_gather_dof.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.crb_solve_rk45.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(InputDesc), vp, vp, i32,
                                  vp]
+    L.crb_solve_rk45_eval.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(InputDesc), vp, vp,
+                                      i32, C.POINTER(RecordDesc), C.c_double, C.c_double, i32, vp]
     L.crb_feedback_force.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crb_rk4_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.POINTER(InputDesc), vp]
     _lib = L

@@ -213,12 +213,16 @@ class BeamEnsemble:
 
     def solve_rk45(self, t_end: float, rtol: float = 1e-3, atol: float = 1e-6, impulse_amp=None,
                    impulse_duration: float = 0.01, impulse_index: int = -2, held_force=None,
-                   first_step=None, t0: Optional[float] = None, max_steps: int = 0):
+                   first_step=None, t0: Optional[float] = None, max_steps: int = 0, record=None, t_eval=None):
         """Integrate every beam from the current clock to ``t_end`` with adaptive Dormand-Prince 5(4),
         per-beam step control, in ONE kernel launch -- the algorithm (and defaults) of
         ``scipy.integrate.solve_ivp(method="RK45")`` that the reference's tests call
         (tests/test_dynamic_beam.py:218-220).  Returns a dict of per-beam statistics:
-        accepted / rejected steps, nfev, status (0 = reached t_end), next_step."""
+        accepted / rejected steps, nfev, status (0 = reached t_end), next_step.
+
+        record=(node, param) with t_eval=(start, step, count): also returns "y" [B, count], that DOF on the
+        uniform grid start + k*step by scipy's dense output (what ``sol.y[i]`` holds when solve_ivp is
+        given ``t_eval=np.arange(...)``, example_utilities.py:158)."""
         if t0 is not None:
             self.time = float(t0)
         desc = nat.InputDesc()
@@ -242,15 +246,26 @@ class BeamEnsemble:
         if first_step is not None:
             h += torch.as_tensor(first_step, dtype=torch.float64, device=self.device)
         stats = torch.zeros((self.n_beams, 4), dtype=torch.int32, device=self.device)
+        rec, ys, grid = None, None, (0.0, 0.0, 0)
+        if record is not None:
+            node, param = record
+            vel = param.startswith("d") and param.endswith("_dt")
+            grid = (float(t_eval[0]), float(t_eval[1]), int(t_eval[2]))
+            ys = torch.zeros((self.n_beams, grid[2]), dtype=self.dtype, device=self.device)
+            rec = nat.RecordDesc(int(vel), int(node), _PARAM[param[1:-3] if vel else param], 1, ys.data_ptr())
         with torch.cuda.device(self.device):
-            nat.check(self._lib.crb_solve_rk45(self.plan.h, self._ptr(self.state), self.time, float(t_end), float(rtol),
-                                               float(atol), C.byref(desc), self._ptr(h), self._ptr(stats), int(max_steps),
-                                               self._stream()))
-        self._keep = keep + [h, stats]
+            nat.check(self._lib.crb_solve_rk45_eval(self.plan.h, self._ptr(self.state), self.time, float(t_end), float(rtol),
+                                                    float(atol), C.byref(desc), self._ptr(h), self._ptr(stats),
+                                                    int(max_steps), C.byref(rec) if rec is not None else None, grid[0],
+                                                    grid[1], grid[2], self._stream()))
+        self._keep = keep + [h, stats, ys]
         self.time = float(t_end)
         st = stats.cpu().numpy()
-        return {"accepted": st[:, 0], "rejected": st[:, 1], "nfev": st[:, 2], "status": st[:, 3],
-                "next_step": h.cpu().numpy()}
+        out = {"accepted": st[:, 0], "rejected": st[:, 1], "nfev": st[:, 2], "status": st[:, 3],
+               "next_step": h.cpu().numpy()}
+        if ys is not None:
+            out["y"] = ys
+        return out
 
     def step_feedback(self, n_steps: int, dt: float, gain, reference=None, impulse_amp=None,
                       impulse_duration: float = 0.01, impulse_index: int = -2, t0: Optional[float] = None) -> float:

@@ -429,6 +429,12 @@ struct Rk45Params {
     int32_t* stats;    // [B][4] accepted, rejected, nfev, status (0 ok, 1 step too small)
     int n_state;       // 2 * n_free: size of the reference's state vector (the error norm's N)
     int max_steps;     // safety bound on attempted steps
+    // dense output of ONE DOF on the uniform grid t_eval[k] = eval_t0 + k*eval_dt, k < n_eval (solve_ivp's
+    // t_eval): after every accepted step the grid points in (t_old, t_new] -- plus t_eval[0] == t0 -- are
+    // evaluated with scipy's 4th-order interpolant (RkDenseOutput, RK45.P) and stored at eval_out[b][k]
+    void* eval_out;    // [B][n_eval] plan dtype, or nullptr
+    double eval_t0, eval_dt;
+    int n_eval, eval_slot, eval_comp;
 };
 
 template <typename T>
@@ -546,6 +552,17 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
     const double B5[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
     const double E5[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
 
+    // scipy RK45.P (dense output): y(t_old + x h) = y_old + h * sum_m x^(m+1) * sum_j K_j P[j][m]
+    const double P5[7][4] = {{1.0, -2.8535800653862835, 3.0717434641059005, -1.1270175653862835},
+                             {0.0, 0.0, 0.0, 0.0},
+                             {0.0, 4.023133379230305, -6.249321565289, 2.675424484351598},
+                             {0.0, -3.7324019615885042, 10.068970589843675, -5.685526961588504},
+                             {0.0, 2.5548038301849423, -6.399112377351017, 3.5219323679207912},
+                             {0.0, -1.3744241142186024, 3.272657752246729, -1.7672812570757455},
+                             {0.0, 1.3824689317781436, -3.764937863556287, 2.382468931778144}};
+    int ie = 0;  // next t_eval index (uniform over the workgroup)
+    const bool recorder = q.eval_out && valid && tp.j == q.eval_slot;
+
     double tc = q.t0;
     int accepted = 0, rejected = 0, nfev = 0, status = 0;
     T k0[6];
@@ -625,6 +642,25 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
                 double factor = (error_norm == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow(error_norm, -0.2));
                 if (step_rejected) factor = fmin(1.0, factor);
                 h_abs *= factor;
+                if (q.eval_out) {  // dense output on the t_eval grid points this step covers
+                    while (ie < q.n_eval) {
+                        const double te = q.eval_t0 + double(ie) * q.eval_dt;
+                        if (te > t_new) break;
+                        if (recorder) {
+                            const double x = (te - tc) / h;
+                            double xp = x, acc = 0.0;
+                            const int c = q.eval_comp;
+                            for (int m = 0; m < 4; ++m) {
+                                double qm = 0.0;
+                                for (int jj = 0; jj < 7; ++jj) qm += double(Ks[(jj * 6 + c) * NT + t]) * P5[jj][m];
+                                acc += qm * xp;
+                                xp *= x;
+                            }
+                            static_cast<T*>(q.eval_out)[size_t(beam) * q.n_eval + ie] = T(h * acc + double(y[c]));
+                        }
+                        ++ie;
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) y[c] = yn[c];
                 putK(0, fn);  // FSAL

@@ -856,7 +856,18 @@ int launch_rk45(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hip
 
 extern "C" int crb_solve_rk45(const crb_plan* p, void* x, double t0, double t_end, double rtol, double atol,
                               const crb_input_desc* in, void* h, void* stats, int max_steps, void* stream) {
+    return crb_solve_rk45_eval(p, x, t0, t_end, rtol, atol, in, h, stats, max_steps, nullptr, 0.0, 0.0, 0, stream);
+}
+
+extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double t_end, double rtol, double atol,
+                                   const crb_input_desc* in, void* h, void* stats, int max_steps,
+                                   const crb_record_desc* rec, double eval_t0, double eval_dt, int n_eval, void* stream) {
     if (int rc = need_device(p, "crb_solve_rk45")) return rc;
+    if (rec && n_eval > 0) {
+        if (rec->plane < 0 || rec->plane > 1 || rec->node < 0 || rec->node >= p->n_node || rec->dof < 0 || rec->dof > 2 ||
+            !rec->out || !(eval_dt > 0) || eval_t0 < t0)
+            return fail(CRB_EINVAL, "crb_solve_rk45_eval: bad t_eval description");
+    }
     if (!x) return fail(CRB_EINVAL, "crb_solve_rk45: null state");
     if (!(t_end > t0)) return fail(CRB_EINVAL, "crb_solve_rk45: t_end must be greater than t0");
     if (!(rtol > 0) || !(atol >= 0)) return fail(CRB_EINVAL, "crb_solve_rk45: tolerances must be positive");
@@ -880,6 +891,10 @@ extern "C" int crb_solve_rk45(const crb_plan* p, void* x, double t0, double t_en
     q.t0 = t0; q.t_end = t_end; q.rtol = rtol; q.atol = atol;
     q.h_io = static_cast<double*>(h); q.stats = static_cast<int32_t*>(stats);
     q.n_state = 2 * p->n_free; q.max_steps = max_steps > 0 ? max_steps : 100000000;
+    q.eval_out = nullptr; q.eval_t0 = eval_t0; q.eval_dt = eval_dt; q.n_eval = 0; q.eval_slot = -1; q.eval_comp = 0;
+    if (rec && n_eval > 0 && rec->node - p->off >= 0) {
+        q.eval_out = rec->out; q.n_eval = n_eval; q.eval_slot = rec->node - p->off; q.eval_comp = rec->plane * 3 + rec->dof;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p->dtype == CRB_F64) {
         KParams<double> k = base_params<double>(p);

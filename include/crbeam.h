@@ -180,6 +180,14 @@ int crb_step_rk4(const crb_plan* plan, void* x, double t0, double dt, int n_step
 int crb_solve_rk45(const crb_plan* plan, void* x, double t0, double t_end, double rtol, double atol,
                    const crb_input_desc* input, void* h, void* stats, int max_steps, void* stream);
 
+/* crb_solve_rk45 plus solve_ivp's `t_eval` for one DOF: values on the uniform grid
+ * t_eval[k] = eval_t0 + k*eval_dt (k < n_eval, eval_t0 >= t0) by scipy's dense output (RkDenseOutput, the
+ * 4th-order interpolant of RK45) -- what the examples read from `sol.y` (example_utilities.py:153-159,
+ * 173-205).  rec->every is unused here; rec->out is device [B][n_eval], plan dtype. */
+int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, double rtol, double atol,
+                        const crb_input_desc* input, void* h, void* stats, int max_steps,
+                        const crb_record_desc* rec, double eval_t0, double eval_dt, int n_eval, void* stream);
+
 /* Feedback force of a whole ensemble, u = K (r - x) (FullStateLinear.compute_input,
  * control/full_state_linear.py:81; loop of examples/lqr_control.py:95-111), as one fp64-MFMA GEMM with the
  * gather from the state layout and the scatter into the force layout fused in (fp64 plans only).

@@ -497,6 +497,15 @@ def g7_rk45():
         out[f"{name}/nfev"] = np.int32(sol.nfev)
         out[f"{name}/accepted"] = np.int32(len(sol.t) - 1)
         out[f"{name}/t_steps"] = sol.t
+        # the same run sampled like the examples do (t_eval=np.arange(...), example_utilities.py:158)
+        n_eval = 37
+        eval_dt = t_end / n_eval
+        sol_e = solve_ivp(lambda t, x: dyn(t, x, u_of_t(t)), (0.0, t_end), np.zeros(2 * n), method="RK45", rtol=rtol,
+                          atol=atol, t_eval=0.0 + np.arange(n_eval) * eval_dt)
+        assert sol_e.success and sol_e.nfev == sol.nfev
+        out[f"{name}/eval_dt"] = np.float64(eval_dt)
+        out[f"{name}/tip_w_eval"] = sol_e.y[n - 2]
+        out[f"{name}/tip_dw_eval"] = sol_e.y[2 * n - 2]
         print(f"G7 {name}: {len(sol.t) - 1} steps, nfev {sol.nfev}, tip w = {sol.y[n - 2, -1]!r} ({time.time() - t_start:.0f} s)")
     np.savez_compressed(os.path.join(HERE, "g7_rk45.npz"), **out)
 

@@ -450,6 +450,15 @@ def test_adaptive_rk45_matches_scipy_on_the_reference_rhs(golden, name):
     got = ens.unpack_state().cpu().numpy()
     assert rel_err(got[0], z[f"{name}/x_final"]) < 1e-8
     assert np.array_equal(got[0], got[2])
+    # t_eval: dense output of the tip displacement / velocity on the grid the golden run was sampled on
+    n_eval = z[f"{name}/tip_w_eval"].size
+    for param, key in (("w", "tip_w_eval"), ("dw_dt", "tip_dw_eval")):
+        ens = ensemble(beam_columns(z, name), B, force_kwargs(z, name))
+        st = ens.solve_rk45(float(z[f"{name}/t_end"]), rtol=float(z[f"{name}/rtol"]), atol=float(z[f"{name}/atol"]),
+                            impulse_amp=np.full(B, float(z[f"{name}/amp"])), impulse_duration=float(z[f"{name}/duration"]),
+                            record=(ens.n_elem, param), t_eval=(0.0, float(z[f"{name}/eval_dt"]), n_eval))
+        y = st["y"].cpu().numpy()
+        assert y.shape == (B, n_eval) and rel_err(y[1], z[f"{name}/{key}"]) < 1e-8
 
 
 def test_adaptive_rk45_per_beam_step_control_matches_scipy_over_oracle():
