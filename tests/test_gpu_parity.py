@@ -485,3 +485,52 @@ def test_adaptive_rk45_per_beam_step_control_matches_scipy_over_oracle():
         sol = solve_ivp(fun, (0.0, t_end), np.zeros(2 * n), method="RK45", rtol=rtol, atol=atol)
         assert st["accepted"][b] == len(sol.t) - 1 and st["nfev"][b] == sol.nfev, (b, st["accepted"][b], len(sol.t) - 1)
         assert rel_err(got[b], sol.y[:, -1]) < 1e-8
+
+
+def test_fp32_plans_run_every_entry_point():
+    """fp32 (BASELINE config 4's dtype) through every API: values track fp64 at single precision."""
+    cols = nitinol_columns(64, "linear")
+    kw = dict(enable_gravity=True, fluid_density=1000.0, enable_fluid=True)
+    B = 3
+    rng = np.random.default_rng(2)
+    e64, e32 = ensemble(cols, B, kw), ensemble(cols, B, kw, dtype=torch.float32)
+    n = e64.n
+    x = rng.normal(0, 1e-3, (B, 2 * n))
+    u = rng.normal(0, 0.1, (B, n))
+    for a, b in ((e64.rhs(x, u), e32.rhs(x, u)), (e64.internal_force(x[:, :n]), e32.internal_force(x[:, :n]))):
+        assert rel_err(b.double().cpu().numpy(), a.cpu().numpy()) < 2e-3  # cond(M) ~ 1e4 in single precision
+    amps = np.array([0.1, 0.2, 0.3])
+    for ens in (e64, e32):
+        ens.zero_state()
+        ens.step(100, 2e-5, impulse_amp=amps, held_force=u * 0.01)
+    assert rel_err(e32.tip_displacement().double().cpu().numpy(), e64.tip_displacement().cpu().numpy()) < 5e-3
+    gain = rng.normal(0, 1e-2, (n, 2 * n))
+    for ens in (e64, e32):
+        ens.zero_state()
+        ens.step_feedback(40, 5e-6, gain, impulse_amp=amps)  # fp64: fused MFMA kernel; fp32: torch.matmul path
+    assert rel_err(e32.tip_displacement().double().cpu().numpy(), e64.tip_displacement().cpu().numpy()) < 5e-3
+    st = {}
+    for name, ens in (("f64", e64), ("f32", e32)):
+        ens.zero_state()
+        st[name] = ens.solve_rk45(4e-4, rtol=1e-3, atol=1e-6, impulse_amp=amps, impulse_duration=2e-4)
+        assert np.all(st[name]["status"] == 0)
+    assert rel_err(e32.tip_displacement().double().cpu().numpy(), e64.tip_displacement().cpu().numpy()) < 2e-2
+
+
+def test_new_entry_points_reject_bad_arguments():
+    from continuum_robot import _native as nat
+
+    ens = ensemble(nitinol_columns(40, "linear"), 2)
+    with pytest.raises(nat.NativeError, match="t_end must be greater"):
+        ens.solve_rk45(0.0)
+    with pytest.raises(nat.NativeError, match="tolerances"):
+        ens.solve_rk45(1e-3, rtol=0.0)
+    small = ensemble(nitinol_columns(8, "linear"), 2)
+    with pytest.raises(nat.NativeError, match="fewer than 33"):
+        small.solve_rk45(1e-3)
+    with pytest.raises(ValueError):
+        ens.step_feedback(1, 5e-6, np.zeros((3, 3)))
+    with pytest.raises(nat.NativeError, match="bad record"):
+        ens.step(10, 2e-5, record=(999, "w"))
+    with pytest.raises(ValueError, match="n_beams entries"):
+        ensemble([nitinol_columns(8, "linear")], 2)
