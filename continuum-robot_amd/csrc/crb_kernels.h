@@ -783,7 +783,7 @@ __device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
     }
 }
 
-template <typename T, int LV, int LOGNW>
+template <typename T, int LV, int LOGNW, bool GRAV>
 // fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: 3 waves/SIMD (168 VGPRs; 4 waves/SIMD spills)
 __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_step_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
@@ -844,6 +844,16 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
     }
     const bool corrected = (p.flags & 4u) != 0;
+    // GRAV: gravity on the canonical cantilever (only node 0 constrained), where the reference's reduced-index
+    // addressing (gravity_forces.py:104-146) is nearest-neighbour: segment j averages the rotations of slots j
+    // and j+1 (slot j alone at the tip) and loads slots j and j+1.  A thread evaluates segment j AND segment
+    // j-1 itself (it knows phi of slots j-1, j, j+1), so gravity needs no exchange of its own.
+    T hm_own = T(0), hm_left = T(0), phiR = T(0);
+    const bool has_right = valid && j + 1 < S;
+    if (GRAV && valid) {
+        hm_own = p.slot[size_t(beam) * p.slot_stride + j].half_mass;
+        if (j >= 1) hm_left = p.slot[size_t(beam) * p.slot_stride + j - 1].half_mass;
+    }
 
     // ---- state
     const size_t node = size_t(valid ? j + p.off : 0);
@@ -866,6 +876,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     if (LOGNW == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(xq[c], lane);  // lane 0 reads 0 = clamped / absent root
+        if (GRAV) phiR = lane_higher<T, 1>(xq[2], lane);
     } else {
         T* rec = ldsA + size_t(t) * RN;
 #pragma unroll
@@ -874,6 +885,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         const T* recl = ldsA + size_t(t_l1) * RN;
 #pragma unroll
         for (int c = 0; c < 3; ++c) qL[c] = recl[c];
+        if (GRAV) phiR = ldsA[size_t(t_r1) * RN + 2];
         __syncthreads();
     }
 
@@ -905,6 +917,13 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 #pragma unroll
             for (int c = 0; c < 3; ++c) pp[c] = ((c == p.imp_dof) ? av : T(0)) - fr[c];
             pp[1] += drag_force<T>(dragc, sv[1]);
+            if (GRAV) {
+                T g_own[2], g_left[2];
+                gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
+                gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+                pp[0] += g_own[0] + g_left[0];
+                pp[1] += g_own[1] + g_left[1];
+            }
 
             // -- round A: publish {qn, p, fl}; rebuild r of this node and of both stride-1 neighbours.
             // Outside the beam a neighbour reads as zeros (DPP edge / all-zero LDS record).
@@ -914,6 +933,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 for (int c = 0; c < 3; ++c) {
                     // (shuffles stay outside any condition: every lane must take part.  Lanes past
                     //  the last slot are padding threads whose p and fl are 0, wave edges shift in 0.)
+                    if (GRAV && c == 2) phiR = lane_higher<T, 1>(qn[2], lane);
                     qL[c] = lane_lower<T, 1>(qn[c], lane);
                     rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
                     r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
@@ -939,8 +959,9 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 __syncthreads();
                 T L[RN], R1[RN], R2[RN];
                 rec_load<T, 0, 6>(bufA + size_t(t_l1) * RN, L);
-                rec_load<T, 4, 9>(bufA + size_t(t_r1) * RN, R1);
+                rec_load<T, GRAV ? 2 : 4, 9>(bufA + size_t(t_r1) * RN, R1);
                 rec_load<T, 7, 9>(bufA + size_t(t_r2) * RN, R2);
+                if (GRAV) phiR = R1[2];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     qL[c] = L[c];

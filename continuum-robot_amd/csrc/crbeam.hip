@@ -30,6 +30,7 @@ struct crb_plan {
     int n_elem = 0, n_node = 0, n_free = 0, off = 0, S = 0, G = 1, NT = 64;
     int levels = 0, levels_full = 0, lognw = 0;
     size_t slot_stride = 0, lv_stride = 0, fin_stride = 0;  // per-beam coefficient tables (0 = shared)
+    bool canonical_gravity = false;  // gravity index table is the nearest-neighbour pattern of the plain cantilever
     uint32_t flags = 0;
     double gx = 0, gy = 0;
     std::vector<int32_t> free_index;  // reduced -> full
@@ -373,6 +374,17 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
 
     p->h_slots = slots;
     p->h_kinds = kinds;
+    if (grav && p->off == 1 && ne == S) {  // does the gravity table reduce to "segment j <-> slots j, j+1"?
+        bool canon = true;
+        for (int j = 0; j < S && canon; ++j) {
+            const GravTab& gt = slots[j].grav;
+            canon = gt.phiA == int16_t(j * 4 + 2) && gt.phiB == (j + 1 < S ? int16_t((j + 1) * 4 + 2) : int16_t(-1)) &&
+                    gt.segA[2] < 0 && gt.segB[2] < 0;
+            for (int c = 0; c < 2 && canon; ++c)
+                canon = gt.comp[c] == c && gt.segA[c] == int16_t(j) && gt.segB[c] == int16_t(j - 1 >= 0 ? j - 1 : -1);
+        }
+        p->canonical_gravity = canon;
+    }
 
     {   // dense reduced stiffness of the linear elements (get_stiffness_matrix); columns = K_e * unit vectors
         p->h_stiff.assign(size_t(n) * n, 0.0);
@@ -643,37 +655,43 @@ int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     }
 }
 
-// Fast path of crb_step_rk4: no gravity tables, no held input, one beam per workgroup.
-template <typename T, int LV, int LOGNW>
+// Fast path of crb_step_rk4: no held input, one beam per workgroup, gravity absent or of the plain
+// cantilever's nearest-neighbour form.
+template <typename T, int LV, int LOGNW, bool GRAV>
 int launch_lean_one(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     const dim3 grid(p->B), block(64 << LOGNW);
     const size_t smem = lean_lds_bytes<T>(64 << LOGNW, LOGNW);
-    if (int rc = allow_lds(crb_step_lean_kernel<T, LV, LOGNW>, smem)) return rc;
-    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW>), grid, block, smem, st, k);
+    if (int rc = allow_lds(crb_step_lean_kernel<T, LV, LOGNW, GRAV>, smem)) return rc;
+    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV>), grid, block, smem, st, k);
     HIP_TRY(hipGetLastError());
     return CRB_OK;
 }
-template <typename T, int LV>
+template <typename T, int LV, bool GRAV>
 int launch_lean_lv(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     switch (p->lognw) {
-        case 0: return launch_lean_one<T, LV, 0>(p, k, st);
-        case 1: return launch_lean_one<T, LV, 1>(p, k, st);
-        case 2: return launch_lean_one<T, LV, 2>(p, k, st);
-        default: return launch_lean_one<T, LV, 3>(p, k, st);
+        case 0: return launch_lean_one<T, LV, 0, GRAV>(p, k, st);
+        case 1: return launch_lean_one<T, LV, 1, GRAV>(p, k, st);
+        case 2: return launch_lean_one<T, LV, 2, GRAV>(p, k, st);
+        default: return launch_lean_one<T, LV, 3, GRAV>(p, k, st);
     }
 }
 inline bool lean_eligible(const crb_plan* p, const void* held) {
-    return !(p->flags & CRB_FORCE_GRAVITY) && !held && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
+    const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
+    return (!grav || p->canonical_gravity) && !held && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
            p->levels >= 3 && p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr;
+}
+template <typename T, bool GRAV>
+int launch_lean_g(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    switch (p->levels) {
+        case 3: return launch_lean_lv<T, 3, GRAV>(p, k, st);
+        case 4: return launch_lean_lv<T, 4, GRAV>(p, k, st);
+        case 5: return launch_lean_lv<T, 5, GRAV>(p, k, st);
+        default: return launch_lean_lv<T, 6, GRAV>(p, k, st);
+    }
 }
 template <typename T>
 int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
-    switch (p->levels) {
-        case 3: return launch_lean_lv<T, 3>(p, k, st);
-        case 4: return launch_lean_lv<T, 4>(p, k, st);
-        case 5: return launch_lean_lv<T, 5>(p, k, st);
-        default: return launch_lean_lv<T, 6>(p, k, st);
-    }
+    return (p->flags & CRB_FORCE_GRAVITY) ? launch_lean_g<T, true>(p, k, st) : launch_lean_g<T, false>(p, k, st);
 }
 
 template <typename T>
