@@ -87,7 +87,7 @@ CRB_HD T plus_remainder(T base, double c, T ww) {
 }
 
 template <typename T>
-CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
+CRB_HD void elem_force_nonlinear_literal(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
     const T L = c[0], A = c[1], D = c[2], iL2 = c[3], tenth_iL3 = c[4];
     const T u1 = ql[0], w1 = ql[1], u2 = qr[0], w2 = qr[1];
     const T a = ql[2] * L, b = qr[2] * L;
@@ -135,6 +135,69 @@ CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool 
     fr[0] = f2;
     fr[1] = -f3;
     fr[2] = f6;
+}
+
+// The same forces in symmetric variables: s = a+b, d = a-b, p = a*b.  Up to the sympy float
+// artefacts above, the shipped polynomials are those of the von Karman element with rational
+// coefficients (1/15, 1/60, 27/7, 72/7, 1/28, 3/28, 9/7, 1/35, 3/280, 1/140, 3/140, 2/15,
+// 1/30, 9/70), f6 is f4 with the two nodes exchanged, and P3 is symmetric in (a, b):
+//   P   = s*(s/15 - dw/20) - p/6
+//   P3  = s*((s^2 - 6p)/28 + L*du - 27/7 dw^2) + dw*(9/7 (s^2 - 2p) - 12 L*du + 72/7 dw^2)
+//   P4+P6 = s*(s^2/40 - 11/140 p - L*du/10 + 9/70 dw^2) + dw*(-3/70 p + L*du/5 - 9/35 dw^2)
+//   P4-P6 = d*(9/280 s^2 - p/20 + 3/140 s*dw - L*du/6 + 9/70 dw^2)
+// which is 62 flops against 135 for the literal form.  Every literal of the reference differs
+// from its rational by <= 1.5e-12 relative (largest: 0.0214285714286007 vs 3/140), i.e. six
+// orders below the 1e-6 parity tolerance; tests/native bounds the difference between the two
+// forms.  -DCRB_LITERAL_POLY=1 builds the kernels with the literal form instead.
+template <typename T>
+CRB_HD void elem_force_nonlinear_sym(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
+    const T L = c[0], A = c[1], D = c[2], iL2 = c[3], tenth_iL3 = c[4];
+    const T u1 = ql[0], u2 = qr[0];
+    const T a = ql[2] * L, b = qr[2] * L;
+    const T du = u1 - u2, dw = ql[1] - qr[1];
+    const T s = a + b, d = a - b, p = a * b;
+    const T s2 = s * s, dw2 = dw * dw, Ldu = L * du;
+
+    // ---- f1, f2 (segments.py:178-208, 227-258)
+    const T T0 = T(0.6) * dw - T(0.05) * s;
+    const T P = s * (T(1.0 / 15.0) * s - T(0.05) * dw) - T(1.0 / 6.0) * p;
+    const T AiL2 = A * iL2;
+    const T f2 = AiL2 * (P - Ldu + dw * T0);
+    const T f1 = corrected ? -f2 : AiL2 * (L * u1 - P - (u2 + dw) * T0);
+
+    // ---- f3 = -f5 (segments.py:279-314, 386-421)
+    const T P3 = s * (T(1.0 / 28.0) * (s2 - T(6.0) * p) + Ldu - T(27.0 / 7.0) * dw2) +
+                 dw * (T(9.0 / 7.0) * (s2 - T(2.0) * p) - T(12.0) * Ldu + T(72.0 / 7.0) * dw2);
+    const T Dg = D * (T(3.0) * s - T(6.0) * dw);   // D*(4a+2b-6dw) = Dg + D*d,  D*(2a+4b-6dw) = Dg - D*d
+    const T f3 = tenth_iL3 * (A * P3 - T(20.0) * Dg);
+
+    // ---- f4, f6 (segments.py:335-365, 442-472)
+    const T S = s * (T(1.0 / 40.0) * s2 - T(11.0 / 140.0) * p - T(0.1) * Ldu + T(9.0 / 70.0) * dw2) +
+                dw * (T(0.2) * Ldu - T(3.0 / 70.0) * p - T(9.0 / 35.0) * dw2);
+    const T R = T(9.0 / 280.0) * s2 - T(0.05) * p + T(3.0 / 140.0) * (s * dw) - T(1.0 / 6.0) * Ldu +
+                T(9.0 / 70.0) * dw2;
+    const T hA = T(0.5) * A;
+    const T X = hA * S + Dg;
+    const T Y = d * (hA * R + D);
+
+    fl[0] = f1;
+    fl[1] = f3;
+    fl[2] = iL2 * (X + Y);
+    fr[0] = f2;
+    fr[1] = -f3;
+    fr[2] = iL2 * (X - Y);
+}
+
+#ifndef CRB_LITERAL_POLY
+#define CRB_LITERAL_POLY 0
+#endif
+template <typename T>
+CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
+#if CRB_LITERAL_POLY
+    elem_force_nonlinear_literal<T>(c, ql, qr, corrected, fl, fr);
+#else
+    elem_force_nonlinear_sym<T>(c, ql, qr, corrected, fl, fr);
+#endif
 }
 
 template <typename T>
