@@ -747,6 +747,23 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 #ifndef CRB_DPP_MAX
 #define CRB_DPP_MAX 2
 #endif
+// wave priorities per phase of a stage (s_setprio; -1 = leave unchanged)
+#ifndef CRB_P_FORCE
+#define CRB_P_FORCE 0
+#endif
+#ifndef CRB_P_XCHG
+#define CRB_P_XCHG 2
+#endif
+#ifndef CRB_P_L1
+#define CRB_P_L1 -1
+#endif
+#ifndef CRB_P_TAIL
+#define CRB_P_TAIL 1
+#endif
+#ifndef CRB_P_FIN
+#define CRB_P_FIN -1
+#endif
+#define CRB_SETPRIO(v) do { if ((v) >= 0) __builtin_amdgcn_s_setprio((v) < 0 ? 0 : (v)); } while (0)
 template <typename T, int D>
 __device__ __forceinline__ T lane_lower(T x, int lane) {
     if (D <= CRB_DPP_MAX) {
@@ -899,7 +916,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const double ts = (s == 0) ? tc : ((s == 3) ? t_full : t_half);
-            const T av = (ts < p.duration) ? amp : T(0);
+            const bool imp_on = ts < p.duration;  // wave-uniform: the impulse selector stays on the scalar unit
             const T w = (s == 0 || s == 3) ? T(1) : T(2);
             const T cs = (s == 2) ? dt : hdt;
 
@@ -912,10 +929,12 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             }
             // -- element force of the element left of this node
             T fl[3], fr[3];
+            CRB_SETPRIO(CRB_P_FORCE);
             elem_force<T>(ec, qL, sq, corrected, fl, fr);
+            CRB_SETPRIO(CRB_P_XCHG);
             T pp[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pp[c] = ((c == p.imp_dof) ? av : T(0)) - fr[c];
+            for (int c = 0; c < 3; ++c) pp[c] = ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];
             pp[1] += drag_force<T>(dragc, sv[1]);
             if (GRAV) {
                 T g_own[2], g_left[2];
@@ -978,6 +997,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             for (int l = 1; l < LV; ++l) {
                 constexpr int dummy = 0; (void)dummy;
                 if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
+                    if (l == 1) CRB_SETPRIO(CRB_P_L1);
                     const int st = 1 << l;
                     T* buf = ldsB + size_t(l - 1) * 3 * (NT + 1);
                     buf[t] = r[0]; buf[(NT + 1) + t] = r[1]; buf[2 * (NT + 1) + t] = r[2];
@@ -987,6 +1007,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
                 } else {
+                    if (l == LOGNW) CRB_SETPRIO(CRB_P_TAIL);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         switch (l - LOGNW) {
@@ -1002,6 +1023,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
             }
             T a[3];
+            CRB_SETPRIO(CRB_P_FIN);
             pcr_apply_final<T>(cf.fin, r, a);
 
             // -- RK4 bookkeeping

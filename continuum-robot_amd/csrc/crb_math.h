@@ -239,9 +239,11 @@ CRB_HD void gravity_segment(T phi, T gx, T gy, T half_mass, T out[2]) {
 }
 
 // Fluid drag on a transverse DOF (fluid_forces.py:138): -c * v * |v|
+CRB_HD double crb_abs(double v) { return __builtin_fabs(v); }
+CRB_HD float crb_abs(float v) { return __builtin_fabsf(v); }
 template <typename T>
 CRB_HD T drag_force(T coef, T v) {
-    return -coef * v * (v < T(0) ? -v : v);
+    return -coef * v * crb_abs(v);
 }
 
 // ------------------------------------------------------------------ mass blocks / PCR

@@ -641,6 +641,9 @@ int launch_beam_lv(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 
 template <typename T, int MODE>
 int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+#ifdef CRB_FAST_BUILD  // kernel-tuning build (make fast): only the config-3 lean stepper is instantiated
+    return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: generic kernels not built");
+#else
     switch (p->levels) {
         case 0: return launch_beam_lv<T, MODE, 0>(p, k, st);
         case 1: return launch_beam_lv<T, MODE, 1>(p, k, st);
@@ -653,6 +656,7 @@ int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
         case 8: return launch_beam_lv<T, MODE, 8>(p, k, st);
         default: return fail(CRB_EUNSUPPORTED, "unsupported number of cyclic-reduction levels");
     }
+#endif
 }
 
 // Fast path of crb_step_rk4: no held input, one beam per workgroup, gravity absent or of the plain
@@ -691,7 +695,13 @@ int launch_lean_g(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 }
 template <typename T>
 int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    if (sizeof(T) == 8 && p->levels == 5 && p->lognw == 2 && !(p->flags & CRB_FORCE_GRAVITY))
+        return launch_lean_one<double, 5, 2, false>(p, reinterpret_cast<const KParams<double>&>(k), st);
+    return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: only <double,5,2,false> is built");
+#else
     return (p->flags & CRB_FORCE_GRAVITY) ? launch_lean_g<T, true>(p, k, st) : launch_lean_g<T, false>(p, k, st);
+#endif
 }
 
 template <typename T>
@@ -859,6 +869,9 @@ int launch_rk45_lv(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, 
 }
 template <typename T>
 int launch_rk45(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: rk45 not built");
+#else
     switch (p->levels) {
         case 0: return launch_rk45_lv<T, 0>(p, k, q, st);
         case 1: return launch_rk45_lv<T, 1>(p, k, q, st);
@@ -869,6 +882,7 @@ int launch_rk45(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hip
         case 6: return launch_rk45_lv<T, 6>(p, k, q, st);
         default: return fail(CRB_EUNSUPPORTED, "crb_solve_rk45: unsupported number of cyclic-reduction levels");
     }
+#endif
 }
 }  // namespace
 

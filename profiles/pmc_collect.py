@@ -1,0 +1,20 @@
+"""Sums rocprofv3 counter_collection CSVs of profiles/pmc_run.sh for the stepper kernel and
+prints them per wave-stage (one wave's share of one RK4 stage = one RHS evaluation)."""
+import csv, glob, json, sys
+
+out, tag = sys.argv[1], sys.argv[2]
+tot, kname, ndisp = {}, None, set()
+for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "crb_step_lean_kernel" not in k and "crb_beam_kernel" not in k:
+            continue
+        kname = k
+        ndisp.add((f, row["Dispatch_Id"]))
+        tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+waves = tot.get("SQ_WAVES", 0.0)
+stages = 200 * 4
+res = {"tag": tag, "kernel": kname, "counters": tot,
+       "per_wave_stage": {k: v / (waves * stages) for k, v in tot.items()} if waves else None}
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(res["per_wave_stage"], indent=1))
