@@ -763,6 +763,9 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 #ifndef CRB_P_FIN
 #define CRB_P_FIN -1
 #endif
+#ifndef CRB_SOA
+#define CRB_SOA 1
+#endif
 #define CRB_SETPRIO(v) do { if ((v) >= 0) __builtin_amdgcn_s_setprio((v) < 0 ? 0 : (v)); } while (0)
 template <typename T, int D>
 __device__ __forceinline__ T lane_lower(T x, int lane) {
@@ -806,6 +809,10 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N, RV = LeanRec<T>::V;
     constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
+    // fp64 round A is laid out as 9 columns [qn0..2 p0..2 fl0..2][NT+1] moved by 8-byte accesses (a 16-byte LDS
+    // store costs 13 cycles of the store path against 2 x 6 for two 8-byte ones); fp32 keeps 16-byte records
+    constexpr bool SOA = CRB_SOA && sizeof(T) == 8;
+    auto recA = [](T* base, int th, int k) -> T& { return SOA ? base[size_t(k) * (NT + 1) + th] : base[size_t(th) * RN + k]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const ldsA = reinterpret_cast<T*>(crb_smem);
     T* const ldsB = ldsA + size_t(NT + 1) * RN * (LOGNW == 1 ? 2 : 1);  // [level-1][3][NT+1]
@@ -824,8 +831,8 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     if (LOGNW > 0 && t == 0) {  // zero the "no neighbour" slots once
 #pragma unroll
         for (int k = 0; k < RN; ++k) {
-            ldsA[size_t(NULLT) * RN + k] = T(0);
-            if (LOGNW == 1) ldsA[size_t(NT + 1) * RN + size_t(NULLT) * RN + k] = T(0);
+            recA(ldsA, NULLT, k) = T(0);
+            if (LOGNW == 1) recA(ldsA + size_t(NT + 1) * RN, NULLT, k) = T(0);
         }
 #pragma unroll
         for (int l = 1; l < LOGNW; ++l)
@@ -895,14 +902,12 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(xq[c], lane);  // lane 0 reads 0 = clamped / absent root
         if (GRAV) phiR = lane_higher<T, 1>(xq[2], lane);
     } else {
-        T* rec = ldsA + size_t(t) * RN;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) rec[c] = xq[c];
+        for (int c = 0; c < 3; ++c) recA(ldsA, t, c) = xq[c];
         __syncthreads();
-        const T* recl = ldsA + size_t(t_l1) * RN;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qL[c] = recl[c];
-        if (GRAV) phiR = ldsA[size_t(t_r1) * RN + 2];
+        for (int c = 0; c < 3; ++c) qL[c] = recA(ldsA, t_l1, c);
+        if (GRAV) phiR = recA(ldsA, t_r1, 2);
         __syncthreads();
     }
 
@@ -960,6 +965,20 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 }
             } else {
                 T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT + 1) * RN : 0);
+                if (SOA) {
+                    recA(bufA, t, 0) = qn[0]; recA(bufA, t, 1) = qn[1]; recA(bufA, t, 2) = qn[2];
+                    recA(bufA, t, 3) = pp[0]; recA(bufA, t, 4) = pp[1]; recA(bufA, t, 5) = pp[2];
+                    recA(bufA, t, 6) = fl[0]; recA(bufA, t, 7) = fl[1]; recA(bufA, t, 8) = fl[2];
+                    __syncthreads();
+                    if (GRAV) phiR = recA(bufA, t_r1, 2);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        qL[c] = recA(bufA, t_l1, c);
+                        rlo[c] = recA(bufA, t_l1, 3 + c) - fl[c];
+                        r[c] = pp[c] - recA(bufA, t_r1, 6 + c);
+                        rhi[c] = recA(bufA, t_r1, 3 + c) - recA(bufA, t_r2, 6 + c);
+                    }
+                } else {
                 typedef typename Vec16<T>::type vec;
                 T out[RN];
                 out[0] = qn[0]; out[1] = qn[1]; out[2] = qn[2]; out[3] = T(0);
@@ -987,6 +1006,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                     rlo[c] = L[4 + c] - fl[c];
                     r[c] = pp[c] - R1[7 + c];
                     rhi[c] = R1[4 + c] - R2[7 + c];
+                }
                 }
             }
             pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
