@@ -73,6 +73,10 @@ struct KParams {
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
+// element kinds over the whole topology: mixed (per-lane branch), all linear, all nonlinear as shipped
+// (CRB_CORRECTED_AXIAL plans take the mixed path).  Threads without an element carry zero coefficients,
+// for which every formula returns zero forces.
+enum : int { EM_MIXED = 0, EM_LINEAR = 1, EM_NONLINEAR = 2 };
 constexpr int MAX_LV = 8;
 
 template <typename T>
@@ -745,7 +749,7 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 // index outside the wave wraps to some lane of the SAME beam -- callers only ever multiply such
 // a value by a multiplier that is exactly 0 (no neighbour at that stride).
 #ifndef CRB_DPP_MAX
-#define CRB_DPP_MAX 2
+#define CRB_DPP_MAX 4
 #endif
 // wave priorities per phase of a stage (s_setprio; -1 = leave unchanged)
 #ifndef CRB_P_FORCE
@@ -803,7 +807,10 @@ __device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
     }
 }
 
-template <typename T, int LV, int LOGNW, bool GRAV>
+// EM (EM_*): the element kind when the whole topology has one; the force evaluation is then straight-line
+// code that the scheduler interleaves with the tail of the previous stage's reduction (measured +8 %
+// over the per-lane branch of EM_MIXED; a wave-uniform run-time branch does not get it).
+template <typename T, int LV, int LOGNW, bool GRAV, int EM>
 // fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: 3 waves/SIMD (168 VGPRs; 4 waves/SIMD spills)
 __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_step_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
@@ -935,7 +942,9 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             // -- element force of the element left of this node
             T fl[3], fr[3];
             CRB_SETPRIO(CRB_P_FORCE);
-            elem_force<T>(ec, qL, sq, corrected, fl, fr);
+            if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
+            else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
+            else elem_force<T>(ec, qL, sq, corrected, fl, fr);
             CRB_SETPRIO(CRB_P_XCHG);
             T pp[3];
 #pragma unroll
@@ -970,14 +979,15 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                     recA(bufA, t, 3) = pp[0]; recA(bufA, t, 4) = pp[1]; recA(bufA, t, 5) = pp[2];
                     recA(bufA, t, 6) = fl[0]; recA(bufA, t, 7) = fl[1]; recA(bufA, t, 8) = fl[2];
                     __syncthreads();
-                    if (GRAV) phiR = recA(bufA, t_r1, 2);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        qL[c] = recA(bufA, t_l1, c);
+                    for (int c = 0; c < 3; ++c) {   // what level 0 needs first, the next stage's qL last
                         rlo[c] = recA(bufA, t_l1, 3 + c) - fl[c];
                         r[c] = pp[c] - recA(bufA, t_r1, 6 + c);
                         rhi[c] = recA(bufA, t_r1, 3 + c) - recA(bufA, t_r2, 6 + c);
                     }
+                    if (GRAV) phiR = recA(bufA, t_r1, 2);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) qL[c] = recA(bufA, t_l1, c);
                 } else {
                 typedef typename Vec16<T>::type vec;
                 T out[RN];

@@ -1,0 +1,63 @@
+// crb_lean.hip -- instantiations and launch of crb_step_lean_kernel for ONE dtype (-DCRB_LEAN_T=double|float).
+#include "crb_lean_launch.h"
+
+#ifndef CRB_LEAN_T
+#error "compile with -DCRB_LEAN_T=double or -DCRB_LEAN_T=float"
+#endif
+
+namespace crb {
+namespace {
+typedef CRB_LEAN_T T;
+
+template <int LV, int LOGNW, bool GRAV, int EM>
+hipError_t one(const KParams<T>& k, int n_beams, hipStream_t st) {
+    const dim3 grid(n_beams), block(64 << LOGNW);
+    const size_t smem = lean_lds_bytes<T>(64 << LOGNW, LOGNW);
+    if (smem > 64 * 1024) {  // dynamic LDS above 64 KiB is opt-in per kernel (the CU has 160 KiB)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM>), grid, block, smem, st, k);
+    return hipGetLastError();
+}
+template <int LV, int LOGNW, bool GRAV>
+hipError_t by_em(const KParams<T>& k, int n_beams, int em, hipStream_t st) {
+    switch (em) {
+        case EM_LINEAR: return one<LV, LOGNW, GRAV, EM_LINEAR>(k, n_beams, st);
+        case EM_NONLINEAR: return one<LV, LOGNW, GRAV, EM_NONLINEAR>(k, n_beams, st);
+        default: return one<LV, LOGNW, GRAV, EM_MIXED>(k, n_beams, st);
+    }
+}
+template <int LV, bool GRAV>
+hipError_t by_nw(const KParams<T>& k, int n_beams, int lognw, int em, hipStream_t st) {
+    switch (lognw) {
+        case 0: return by_em<LV, 0, GRAV>(k, n_beams, em, st);
+        case 1: return by_em<LV, 1, GRAV>(k, n_beams, em, st);
+        case 2: return by_em<LV, 2, GRAV>(k, n_beams, em, st);
+        case 3: return by_em<LV, 3, GRAV>(k, n_beams, em, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <bool GRAV>
+hipError_t by_lv(const KParams<T>& k, int n_beams, int levels, int lognw, int em, hipStream_t st) {
+    switch (levels) {
+        case 3: return by_nw<3, GRAV>(k, n_beams, lognw, em, st);
+        case 4: return by_nw<4, GRAV>(k, n_beams, lognw, em, st);
+        case 5: return by_nw<5, GRAV>(k, n_beams, lognw, em, st);
+        case 6: return by_nw<6, GRAV>(k, n_beams, lognw, em, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+}  // namespace
+
+hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st) {
+#ifdef CRB_FAST_BUILD  // kernel-tuning build (make fast): only the config-3 instance
+    if (sizeof(T) == 8 && levels == 5 && lognw == 2 && !grav && elem_mode == EM_NONLINEAR)
+        return one<5, 2, false, EM_NONLINEAR>(k, n_beams, st);
+    return hipErrorInvalidValue;
+#else
+    return grav ? by_lv<true>(k, n_beams, levels, lognw, elem_mode, st) : by_lv<false>(k, n_beams, levels, lognw, elem_mode, st);
+#endif
+}
+}  // namespace crb

@@ -1,0 +1,13 @@
+// crb_lean_launch.h -- host entry of the lean stepper's translation units (crb_lean.hip is compiled once
+// per dtype so that the kernel instantiations build in parallel with the rest of the library).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "crb_kernels.h"
+
+namespace crb {
+// launches crb_step_lean_kernel<T, levels, lognw, grav, elem_mode> on `n_beams` workgroups.
+// levels in 3..6, lognw in 0..3 (callers check eligibility); hipErrorInvalidValue otherwise.
+hipError_t launch_lean(const KParams<double>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
+hipError_t launch_lean(const KParams<float>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
+}  // namespace crb

@@ -11,6 +11,7 @@
 
 #include "../../include/crbeam.h"
 #include "crb_kernels.h"
+#include "crb_lean_launch.h"
 
 using namespace crb;
 
@@ -32,6 +33,7 @@ struct crb_plan {
     size_t slot_stride = 0, lv_stride = 0, fin_stride = 0;  // per-beam coefficient tables (0 = shared)
     bool canonical_gravity = false;  // gravity index table is the nearest-neighbour pattern of the plain cantilever
     uint32_t flags = 0;
+    int elem_mode = 0;           // EM_* (crb_kernels.h)
     double gx = 0, gy = 0;
     std::vector<int32_t> free_index;  // reduced -> full
     std::vector<int32_t> full2red;    // full -> reduced or -1
@@ -374,6 +376,13 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
 
     p->h_slots = slots;
     p->h_kinds = kinds;
+    {   // one element kind over the whole topology?
+        bool all_nl = true, all_lin = true;
+        for (int b = 0; b < nd; ++b)   // every beam of a per-beam-coefficient ensemble
+            for (int e = 0; e < ne; ++e) { all_nl = all_nl && d[b].nonlinear[e]; all_lin = all_lin && !d[b].nonlinear[e]; }
+        p->elem_mode = all_lin ? EM_LINEAR : (all_nl && !(d->flags & CRB_CORRECTED_AXIAL)) ? EM_NONLINEAR : EM_MIXED;
+        if (std::getenv("CRB_DISABLE_ELEM_MODE")) p->elem_mode = EM_MIXED;
+    }
     if (grav && p->off == 1 && ne == S) {  // does the gravity table reduce to "segment j <-> slots j, j+1"?
         bool canon = true;
         for (int j = 0; j < S && canon; ++j) {
@@ -660,48 +669,20 @@ int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 }
 
 // Fast path of crb_step_rk4: no held input, one beam per workgroup, gravity absent or of the plain
-// cantilever's nearest-neighbour form.
-template <typename T, int LV, int LOGNW, bool GRAV>
-int launch_lean_one(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
-    const dim3 grid(p->B), block(64 << LOGNW);
-    const size_t smem = lean_lds_bytes<T>(64 << LOGNW, LOGNW);
-    if (int rc = allow_lds(crb_step_lean_kernel<T, LV, LOGNW, GRAV>, smem)) return rc;
-    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV>), grid, block, smem, st, k);
-    HIP_TRY(hipGetLastError());
-    return CRB_OK;
-}
-template <typename T, int LV, bool GRAV>
-int launch_lean_lv(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
-    switch (p->lognw) {
-        case 0: return launch_lean_one<T, LV, 0, GRAV>(p, k, st);
-        case 1: return launch_lean_one<T, LV, 1, GRAV>(p, k, st);
-        case 2: return launch_lean_one<T, LV, 2, GRAV>(p, k, st);
-        default: return launch_lean_one<T, LV, 3, GRAV>(p, k, st);
-    }
-}
+// cantilever's nearest-neighbour form.  The kernels live in crb_lean.hip (one translation unit per dtype).
 inline bool lean_eligible(const crb_plan* p, const void* held) {
     const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
     return (!grav || p->canonical_gravity) && !held && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
            p->levels >= 3 && p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr;
 }
-template <typename T, bool GRAV>
-int launch_lean_g(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
-    switch (p->levels) {
-        case 3: return launch_lean_lv<T, 3, GRAV>(p, k, st);
-        case 4: return launch_lean_lv<T, 4, GRAV>(p, k, st);
-        case 5: return launch_lean_lv<T, 5, GRAV>(p, k, st);
-        default: return launch_lean_lv<T, 6, GRAV>(p, k, st);
-    }
-}
 template <typename T>
 int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 #ifdef CRB_FAST_BUILD
-    if (sizeof(T) == 8 && p->levels == 5 && p->lognw == 2 && !(p->flags & CRB_FORCE_GRAVITY))
-        return launch_lean_one<double, 5, 2, false>(p, reinterpret_cast<const KParams<double>&>(k), st);
-    return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: only <double,5,2,false> is built");
-#else
-    return (p->flags & CRB_FORCE_GRAVITY) ? launch_lean_g<T, true>(p, k, st) : launch_lean_g<T, false>(p, k, st);
+    if constexpr (sizeof(T) == 4) return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: fp32 lean stepper not built");
+    else
 #endif
+    HIP_TRY(crb::launch_lean(k, p->B, p->levels, p->lognw, (p->flags & CRB_FORCE_GRAVITY) != 0, p->elem_mode, st));
+    return CRB_OK;
 }
 
 template <typename T>
