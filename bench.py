@@ -29,9 +29,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-FP64_VALU_PEAK_TF = 78.6       # public MI355X vector fp64 figure
+VALU_CLOCK_HZ = 2.4e9          # nominal engine clock (the chip holds ~2.2 GHz under this fp64 load)
 BYTES_PER_ELEM_STEP = {torch.float64: 96.0, torch.float32: 48.0}
-FLOP_PER_ELEM_STEP = {"nonlinear": 1.9e3, "linear": 1.0e3}  # SURVEY §8(d) algorithmic estimate
 
 CONFIGS = {
     # name: (beams per GPU, elements, element type, force kwargs, random x0, default steps)
@@ -285,13 +284,11 @@ def main():
                        "plan_ms": plan_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("crb_step_lean_kernel" if not cfg["gravity"] else
-                                    ("crb_beam_kernel<MODE_STAGE> + GEMM" if gain is not None else "crb_beam_kernel<MODE_STEP>")),
+                         "kernel": ("crb_beam_kernel<MODE_STAGE> + crb_feedback_kernel" if gain is not None
+                                    else "crb_step_lean_kernel"),
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "valu_fp64_frac_estimate": (FLOP_PER_ELEM_STEP[cfg["kind"]] * B * ne
-                                                     * min(per_launch, args.steps) / avg_launch_s / 1e12)
-                         / FP64_VALU_PEAK_TF if dtype == torch.float64 else None},
+                         "valu_issue_frac": None},
             "check": check,
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
@@ -302,6 +299,12 @@ def main():
                 if key in tj:
                     out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tj[key].get("source")
+                    if "valu_instr_per_elem_step" in tj[key]:
+                        # the limiter that actually binds: vector-ALU issue slots (one wave instruction per
+                        # SIMD every 4 cycles, 1024 SIMDs, nominal 2.4 GHz), instruction count from the PMC run
+                        lane_instr = tj[key]["valu_instr_per_elem_step"] * B * ne * min(per_launch, args.steps) / avg_launch_s
+                        out["roofline"]["valu_issue_frac"] = lane_instr / (1024 * 64 * VALU_CLOCK_HZ / 4)
+                        out["roofline"]["valu_source"] = tj[key].get("valu_source")
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
