@@ -22,7 +22,8 @@ enum : int { KIND_NONE = 0, KIND_LINEAR = 1, KIND_NONLINEAR = 2 };
 // Per-element coefficient pack (a1/a3 of SURVEY §8).  One element = the element to the
 // LEFT of a slot's node.
 //   linear    : c = { EA/L, 12EI/L^3, 6EI/L^2, 4EI/L, 2EI/L, 0 }        (segments.py:32-62)
-//   nonlinear : c = { L, EA, EI, 1/L^2, 0.1/L^3, 0 }                     (segments.py:128-130)
+//   nonlinear : c = { L, EA/L^2, 0.1 EA/L^3, 2 EI/L^3, EA/(2L^2), EI/L^2 } (segments.py:128-130; the
+//               products of EA, EI and the 1/L^2, 0.1/L^3 prefactors the six forces use)
 template <typename T>
 struct ElemCoef {
     T c[6];
@@ -43,12 +44,13 @@ CRB_HD void elem_coef_build(ElemCoef<T>& e, int kind, double L, double E, double
         e.c[4] = T(2 * EI / L);
         e.c[5] = T(0);
     } else if (kind == KIND_NONLINEAR) {
+        const double iL2 = 1.0 / (L * L), tenth_iL3 = 0.1 / (L * L * L);
         e.c[0] = T(L);
-        e.c[1] = T(EA);
-        e.c[2] = T(EI);
-        e.c[3] = T(1.0 / (L * L));
-        e.c[4] = T(0.1 / (L * L * L));
-        e.c[5] = T(0);
+        e.c[1] = T(EA * iL2);
+        e.c[2] = T(EA * tenth_iL3);
+        e.c[3] = T(20.0 * EI * tenth_iL3);
+        e.c[4] = T(0.5 * EA * iL2);
+        e.c[5] = T(EI * iL2);
     } else {
         for (int i = 0; i < 6; ++i) e.c[i] = T(0);
     }
@@ -86,6 +88,7 @@ CRB_HD T plus_remainder(T base, double c, T ww) {
     return c == 0.0 ? base : base + T(c) * ww;
 }
 
+// (literal form: c = { L, EA, EI, 1/L^2, 0.1/L^3 }, not the ElemCoef pack)
 template <typename T>
 CRB_HD void elem_force_nonlinear_literal(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
     const T L = c[0], A = c[1], D = c[2], iL2 = c[3], tenth_iL3 = c[4];
@@ -145,47 +148,45 @@ CRB_HD void elem_force_nonlinear_literal(const T* c, const T ql[3], const T qr[3
 //   P3  = s*((s^2 - 6p)/28 + L*du - 27/7 dw^2) + dw*(9/7 (s^2 - 2p) - 12 L*du + 72/7 dw^2)
 //   P4+P6 = s*(s^2/40 - 11/140 p - L*du/10 + 9/70 dw^2) + dw*(-3/70 p + L*du/5 - 9/35 dw^2)
 //   P4-P6 = d*(9/280 s^2 - p/20 + 3/140 s*dw - L*du/6 + 9/70 dw^2)
-// which is 62 flops against 135 for the literal form.  Every literal of the reference differs
+// which is 57 flops (with the prefactor products of the ElemCoef pack) against 135 for the literal form.  Every literal of the reference differs
 // from its rational by <= 1.5e-12 relative (largest: 0.0214285714286007 vs 3/140), i.e. six
 // orders below the 1e-6 parity tolerance; tests/native bounds the difference between the two
 // forms.  -DCRB_LITERAL_POLY=1 builds the kernels with the literal form instead.
 template <typename T>
 CRB_HD void elem_force_nonlinear_sym(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
-    const T L = c[0], A = c[1], D = c[2], iL2 = c[3], tenth_iL3 = c[4];
+    const T L = c[0], cA1 = c[1], cA3 = c[2], cD3 = c[3], cA4 = c[4], cD4 = c[5];
     const T u1 = ql[0], u2 = qr[0];
     const T a = ql[2] * L, b = qr[2] * L;
     const T du = u1 - u2, dw = ql[1] - qr[1];
     const T s = a + b, d = a - b, p = a * b;
     const T s2 = s * s, dw2 = dw * dw, Ldu = L * du;
 
-    // ---- f1, f2 (segments.py:178-208, 227-258)
+    // ---- f1, f2 (segments.py:178-208, 227-258): EA/L^2 * (...)
     const T T0 = T(0.6) * dw - T(0.05) * s;
     const T P = s * (T(1.0 / 15.0) * s - T(0.05) * dw) - T(1.0 / 6.0) * p;
-    const T AiL2 = A * iL2;
-    const T f2 = AiL2 * (P - Ldu + dw * T0);
-    const T f1 = corrected ? -f2 : AiL2 * (L * u1 - P - (u2 + dw) * T0);
+    const T f2 = cA1 * (P - Ldu + dw * T0);
+    const T f1 = corrected ? -f2 : cA1 * (L * u1 - P - (u2 + dw) * T0);
 
-    // ---- f3 = -f5 (segments.py:279-314, 386-421)
+    // ---- f3 = -f5 (segments.py:279-314, 386-421): 0.1/L^3 * (EA*P3 + EI*(120 dw - 60 s))
     const T P3 = s * (T(1.0 / 28.0) * (s2 - T(6.0) * p) + Ldu - T(27.0 / 7.0) * dw2) +
                  dw * (T(9.0 / 7.0) * (s2 - T(2.0) * p) - T(12.0) * Ldu + T(72.0 / 7.0) * dw2);
-    const T Dg = D * (T(3.0) * s - T(6.0) * dw);   // D*(4a+2b-6dw) = Dg + D*d,  D*(2a+4b-6dw) = Dg - D*d
-    const T f3 = tenth_iL3 * (A * P3 - T(20.0) * Dg);
+    const T g = T(3.0) * s - T(6.0) * dw;   // 4a+2b-6dw = g + d,  2a+4b-6dw = g - d,  120dw-60s = -20 g
+    const T f3 = cA3 * P3 - cD3 * g;
 
-    // ---- f4, f6 (segments.py:335-365, 442-472)
+    // ---- f4, f6 (segments.py:335-365, 442-472): 1/L^2 * (EA*P4|6 + EI*(g +- d))
     const T S = s * (T(1.0 / 40.0) * s2 - T(11.0 / 140.0) * p - T(0.1) * Ldu + T(9.0 / 70.0) * dw2) +
                 dw * (T(0.2) * Ldu - T(3.0 / 70.0) * p - T(9.0 / 35.0) * dw2);
     const T R = T(9.0 / 280.0) * s2 - T(0.05) * p + T(3.0 / 140.0) * (s * dw) - T(1.0 / 6.0) * Ldu +
                 T(9.0 / 70.0) * dw2;
-    const T hA = T(0.5) * A;
-    const T X = hA * S + Dg;
-    const T Y = d * (hA * R + D);
+    const T X = cA4 * S + cD4 * g;
+    const T Y = d * (cA4 * R + cD4);
 
     fl[0] = f1;
     fl[1] = f3;
-    fl[2] = iL2 * (X + Y);
+    fl[2] = X + Y;
     fr[0] = f2;
     fr[1] = -f3;
-    fr[2] = iL2 * (X - Y);
+    fr[2] = X - Y;
 }
 
 #ifndef CRB_LITERAL_POLY
@@ -194,7 +195,9 @@ CRB_HD void elem_force_nonlinear_sym(const T* c, const T ql[3], const T qr[3], b
 template <typename T>
 CRB_HD void elem_force_nonlinear(const T* c, const T ql[3], const T qr[3], bool corrected, T fl[3], T fr[3]) {
 #if CRB_LITERAL_POLY
-    elem_force_nonlinear_literal<T>(c, ql, qr, corrected, fl, fr);
+    const T iL2 = T(1) / (c[0] * c[0]);
+    const T lit[5] = {c[0], c[1] / iL2, c[5] / iL2, iL2, T(0.1) * iL2 / c[0]};
+    elem_force_nonlinear_literal<T>(lit, ql, qr, corrected, fl, fr);
 #else
     elem_force_nonlinear_sym<T>(c, ql, qr, corrected, fl, fr);
 #endif

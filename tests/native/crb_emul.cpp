@@ -30,10 +30,14 @@ void emul_elem_force_f32(int kind, double L, double E, double I, double A, const
 // 1 symmetric variables with rational coefficients (the form the kernels use)
 void emul_elem_nonlinear_form(int which, double L, double E, double I, double A, const double* ql, const double* qr,
                               int corrected, double* fl, double* fr) {
-    ElemCoef<double> e;
-    elem_coef_build<double>(e, KIND_NONLINEAR, L, E, I, A);
-    if (which == 0) elem_force_nonlinear_literal<double>(e.c, ql, qr, corrected != 0, fl, fr);
-    else            elem_force_nonlinear_sym<double>(e.c, ql, qr, corrected != 0, fl, fr);
+    if (which == 0) {
+        const double lit[5] = {L, E * A, E * I, 1.0 / (L * L), 0.1 / (L * L * L)};
+        elem_force_nonlinear_literal<double>(lit, ql, qr, corrected != 0, fl, fr);
+    } else {
+        ElemCoef<double> e;
+        elem_coef_build<double>(e, KIND_NONLINEAR, L, E, I, A);
+        elem_force_nonlinear_sym<double>(e.c, ql, qr, corrected != 0, fl, fr);
+    }
 }
 void emul_gravity_segment(double phi, double gx, double gy, double half_mass, double* out) {
     gravity_segment<double>(phi, gx, gy, half_mass, out);
