@@ -192,6 +192,26 @@ def test_lean_stepper_sizes(n_e, B):
     assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
 
 
+@pytest.mark.parametrize("kind", ["linear", "nonlinear"])
+@pytest.mark.parametrize("n_e,root", [(64, "FIXED"), (128, "FIXED"), (256, "FIXED"), (512, "FIXED"),
+                                      (100, "PINNED"), (200, "NONE")])
+def test_lean_stepper_single_kind_topologies(kind, n_e, root):
+    """Beams of ONE element kind take the lean stepper's straight-line force code (element mode
+    EM_LINEAR / EM_NONLINEAR, crb_kernels.h) for every waves-per-beam count.  With a root that keeps its
+    slot (PINNED or unconstrained) the first thread has no element to its left and runs the same formula
+    on zero coefficients."""
+    cols = nitinol_columns(n_e, kind, [root] + ["NONE"] * (n_e - 1))
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    B = 3
+    amps = 0.05 * (1.0 + np.arange(B))
+    ob = oracle_beam(cols, **kw)
+    ens = ensemble(cols, B, kw)
+    steps = 100
+    ens.step(steps, 2e-5, impulse_amp=amps)
+    ref, _ = ob.rk4_impulse_batch(np.zeros((B, 2 * ob.n)), 2e-5, steps, amps)
+    assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
+
+
 def test_corrected_axial_option_matches_oracle():
     cols = nitinol_columns(16, "nonlinear")
     ob = oracle_beam(cols, corrected_axial=True)
