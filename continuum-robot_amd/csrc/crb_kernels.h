@@ -1234,68 +1234,146 @@ struct FeedbackParams {
     int B, n, n2;           // n2 = 2n
     size_t x_stride, u_stride;
 };
-constexpr int FB_BK = 64, FB_LD = FB_BK + 2;
-
-// BM x BN outputs per 256-thread workgroup (4 waves as 2 x 2, each (BM/2) x (BN/2) = TM x TN MFMA tiles)
-template <int BM, int BN>
+// BM x BN outputs per 256-thread workgroup; the 4 waves form a WR x (4/WR) grid, each wave owning
+// (BM/WR) x (BN/WC) outputs = TM x TN MFMA tiles of 16 x 16.  K advances in steps of BK through two LDS
+// stages (one barrier per step).  The global loads of step s+1 are issued BEFORE the MFMAs of step s and
+// only touched (negated, masked, stored to LDS) AFTER them, so they fly during the matrix work; every load is
+// unconditional (rows / columns out of range read a clamped address and are zeroed by a select) -- a load
+// under a per-lane branch would be followed by s_waitcnt vmcnt(0) inside the branch.  The reduced-index ->
+// state-offset table sits in LDS.
+#ifndef CRB_GEMM_SCHED
+#define CRB_GEMM_SCHED 0
+#endif
+template <int BM, int BN, int BK, int WR, bool HAS_REF>
 __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams p) {
-    constexpr int TM = BM / 32, TN = BN / 32, QA = BM * FB_BK / 256, QB = BN * FB_BK / 256, RSTEP = 256 / FB_BK;
-    __shared__ __attribute__((aligned(16))) double As[BM * FB_LD];
-    __shared__ __attribute__((aligned(16))) double Bs[BN * FB_LD];
+    constexpr int WC = 4 / WR, TM = BM / (16 * WR), TN = BN / (16 * WC), LD = BK + 2;
+    constexpr int QA = BM * BK / 256, QB = BN * BK / 256, RSTEP = 256 / BK;
+    static_assert(BM % (16 * WR) == 0 && BN % (16 * WC) == 0 && 256 % BK == 0 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
+    double* const As = reinterpret_cast<double*>(crb_smem);          // [2][BM * LD]
+    double* const Bs = As + 2 * BM * LD;                             // [2][BN * LD]
+    int32_t* const coff_s = reinterpret_cast<int32_t*>(Bs + 2 * BN * LD);  // [n2]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int wm = (wave / WC) * (BM / WR), wn = (wave % WC) * (BN / WC);
+    for (int k = t; k < p.n2; k += 256) coff_s[k] = p.col_off[k];
     crb_d4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = crb_d4{0.0, 0.0, 0.0, 0.0};
 
-    // loader: this thread fetches column lk of rows lr, lr+8, .. of both tiles; the values of K-step
-    // s+1 are in flight (registers) while the MFMAs of step s run out of LDS
-    const int lk = t & (FB_BK - 1), lr = t / FB_BK;
-    double ea[QA], gb[QB];
-    auto fetch = [&](int k0) {
+    // loader: this thread fetches column lk of rows lr + RSTEP*q of both tiles
+    const int lk = t & (BK - 1), lr = t / BK;
+    const double* xrow[QA];
+    const double* rrow[QA];
+    const double* grow[QB];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+        const int b = m0 + lr + RSTEP * q;
+        const int bc = b < p.B ? b : p.B - 1;
+        xrow[q] = p.xs + size_t(bc) * p.x_stride;
+        rrow[q] = HAS_REF ? p.ref + size_t(bc) * p.n2 : nullptr;
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int i = n0 + lr + RSTEP * q;
+        grow[q] = p.gain + size_t(i < p.n ? i : p.n - 1) * p.n2;
+    }
+    __syncthreads();  // coff_s
+    // Three-deep pipeline over K steps: while the MFMAs of step s run out of LDS stage s&1, the values of
+    // step s+1 (loaded one iteration ago, now in registers) are negated / masked / stored into stage (s+1)&1
+    // piecewise BETWEEN the MFMA groups, and the global loads of step s+2 are in flight.
+    // Out-of-range ROWS of either tile need no masking (their outputs are never stored); the K tail is
+    // zeroed on the gain side only, by a multiplication (a per-lane select on k would come back as a
+    // branch and split the scheduling region).  Without a reference the A tile holds +x and the sign goes
+    // into the epilogue: the state goes from global memory to LDS untouched.
+    struct Regs { double xa[QA], ra[QA], gb[QB]; double kmask; };
+    Regs R0, R1;
+    auto fetch = [&](Regs& R, int k0) {
         const int k = k0 + lk;
         const bool kok = k < p.n2;
-        const int coff = kok ? p.col_off[k] : 0;
+        R.kmask = kok ? 1.0 : 0.0;
+        const int kc = kok ? k : 0;
+        const int coff = coff_s[kc];
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
-            const int b = m0 + lr + RSTEP * q;
-            double e = 0.0;
-            if (kok && b < p.B) {
-                e = -p.xs[size_t(b) * p.x_stride + coff];
-                if (p.ref) e += p.ref[size_t(b) * p.n2 + k];
-            }
-            ea[q] = e;
+            R.xa[q] = xrow[q][coff];
+            if (HAS_REF) R.ra[q] = rrow[q][kc];
         }
 #pragma unroll
-        for (int q = 0; q < QB; ++q) {
-            const int i = n0 + lr + RSTEP * q;
-            gb[q] = (kok && i < p.n) ? p.gain[size_t(i) * p.n2 + k] : 0.0;
+        for (int q = 0; q < QB; ++q) R.gb[q] = grow[q][kc];
+    };
+    auto stash_piece = [&](const Regs& R, int st, int piece) {   // element `piece` of the QA + QB this thread stores
+        double* A = As + st * BM * LD;
+        double* Bt = Bs + st * BN * LD;
+        if (piece < QA) {
+            const int q = piece;
+            A[(lr + RSTEP * q) * LD + lk] = HAS_REF ? R.ra[q] - R.xa[q] : R.xa[q];
+        } else if (piece < QA + QB) {
+            const int q = piece - QA;
+            Bt[(lr + RSTEP * q) * LD + lk] = R.gb[q] * R.kmask;
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < p.n2; k0 += FB_BK) {
+    constexpr int NSUB = BK / 4, NPIECE = QA + QB, PPS = (NPIECE + NSUB - 1) / NSUB;   // pieces per MFMA sub-step
+    // split K: slice blockIdx.z of gridDim.z takes a contiguous range of K steps; with two slices the partial
+    // sums are added into a zeroed U by fp64 atomics (0 + a + b == 0 + b + a bit for bit: still deterministic)
+    const int all_steps = (p.n2 + BK - 1) / BK;
+    const int per_slice = (all_steps + int(gridDim.z) - 1) / int(gridDim.z);
+    const int kbase = int(blockIdx.z) * per_slice * BK;
+    const int nsteps = min(per_slice, all_steps - int(blockIdx.z) * per_slice);
+    fetch(R0, kbase);
 #pragma unroll
-        for (int q = 0; q < QA; ++q) As[(lr + RSTEP * q) * FB_LD + lk] = ea[q];
+    for (int piece = 0; piece < NPIECE; ++piece) stash_piece(R0, 0, piece);
+    fetch(R1, kbase + BK);
+    __syncthreads();
+    auto step = [&](Regs& Rcur /* step s+1 */, Regs& Rnxt /* receives step s+2 */, int sidx) {
+        const int st = sidx & 1;
+        // (no conditions here: past the end fetch() reads clamped addresses and the stash fills an LDS stage
+        //  that nobody reads any more -- one basic block, so that the interleave below can be enforced)
+        fetch(Rnxt, kbase + (sidx + 2) * BK);
+        const double* Aw = As + st * BM * LD + (wm + (lane & 15)) * LD + (lane >> 4);
+        const double* Bw = Bs + st * BN * LD + (wn + (lane & 15)) * LD + (lane >> 4);
+        double af[2][TM], bf[2][TN];   // fragments of sub-step kk+4 are read while the MFMAs of sub-step kk run
 #pragma unroll
-        for (int q = 0; q < QB; ++q) Bs[(lr + RSTEP * q) * FB_LD + lk] = gb[q];
-        __syncthreads();
-        if (k0 + FB_BK < p.n2) fetch(k0 + FB_BK);
+        for (int a = 0; a < TM; ++a) af[0][a] = Aw[16 * a * LD];
 #pragma unroll
-        for (int kk = 0; kk < FB_BK; kk += 4) {
-            double af[TM], bf[TN];
+        for (int b = 0; b < TN; ++b) bf[0][b] = Bw[16 * b * LD];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = As[(wm + 16 * a + (lane & 15)) * FB_LD + kk + (lane >> 4)];
+        for (int kk = 0; kk < BK; kk += 4) {
+            const int cur = (kk >> 2) & 1, nxt = cur ^ 1;
+            if (kk + 4 < BK) {
 #pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = Bs[(wn + 16 * b + (lane & 15)) * FB_LD + kk + (lane >> 4)];
+                for (int a = 0; a < TM; ++a) af[nxt][a] = Aw[16 * a * LD + kk + 4];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bf[nxt][b] = Bw[16 * b * LD + kk + 4];
+            }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PPS; ++i) stash_piece(Rcur, st ^ 1, (kk >> 2) * PPS + i);
         }
+#if CRB_GEMM_SCHED
+        // a wave issues in order: an MFMA holds the matrix pipe for 64 cycles, and whatever follows it in
+        // program order can issue in that shadow only if it is not another MFMA.  Ask the scheduler for
+        // MFMA / LDS read / VALU / global load / LDS write round-robin instead of MFMA clusters.
+#pragma unroll
+        for (int i = 0; i < NSUB * TM * TN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#endif
         __syncthreads();
+    };
+    for (int sidx = 0; sidx < nsteps; sidx += 2) {
+        step(R1, R0, sidx);
+        if (sidx + 1 < nsteps) step(R0, R1, sidx + 1);
     }
     // epilogue: D row (beam) = (lane>>4) + 4*reg, D col (output) = lane&15; scatter into the force layout
 #pragma unroll
@@ -1308,9 +1386,18 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int beam = m0 + wm + 16 * a + (lane >> 4) + 4 * reg;
-                if (beam < p.B) p.u[size_t(beam) * p.u_stride + roff] = acc[a][b][reg];
+                if (beam < p.B) {
+                    const double v = HAS_REF ? acc[a][b][reg] : -acc[a][b][reg];
+                    double* dst = p.u + size_t(beam) * p.u_stride + roff;
+                    if (gridDim.z > 1) unsafeAtomicAdd(dst, v);
+                    else *dst = v;
+                }
             }
         }
+}
+template <int BM, int BN, int BK>
+__host__ __device__ constexpr size_t feedback_lds_bytes(int n2) {
+    return size_t(2) * (BM + BN) * (BK + 2) * sizeof(double) + size_t(n2) * sizeof(int32_t);
 }
 
 // ------------------------------------------------------------------ layout conversion

@@ -921,6 +921,33 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
     return launch_rk45<float>(p, k, q, st);
 }
 
+namespace {
+template <int BM, int BN, int BK, int WR>
+int launch_feedback_tile(const FeedbackParams& f, int ksplit, hipStream_t st) {
+    const dim3 grid((f.B + BM - 1) / BM, (f.n + BN - 1) / BN, ksplit);
+    const size_t smem = feedback_lds_bytes<BM, BN, BK>(f.n2);
+    if (ksplit > 1) HIP_TRY(hipMemsetAsync(f.u, 0, size_t(f.B) * f.u_stride * sizeof(double), st));
+    if (f.ref) {
+        if (int rc = allow_lds(crb_feedback_kernel<BM, BN, BK, WR, true>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_kernel<BM, BN, BK, WR, true>), grid, dim3(256), smem, st, f);
+    } else {
+        if (int rc = allow_lds(crb_feedback_kernel<BM, BN, BK, WR, false>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_kernel<BM, BN, BK, WR, false>), grid, dim3(256), smem, st, f);
+    }
+    return CRB_OK;
+}
+// tile: 0 = choose.  64 x 48 (BK 64) gives the config-5 shape one workgroup per CU and the fewest L2
+// reads (33 us at 2048 x 768 x 384 against 37 us for 32 x 32); small ensembles take 32 x 32 for the
+// larger grid.  CRB_FEEDBACK_TILE=48|32 forces one (tests cover both).
+int launch_feedback(int tile, const FeedbackParams& f, hipStream_t st) {
+    const long wide_groups = long((f.B + 63) / 64) * ((f.n + 47) / 48);
+    const bool wide_fits = feedback_lds_bytes<64, 48, 64>(f.n2) <= size_t(160) * 1024;
+    if (tile == 0) tile = (wide_groups >= 192 && wide_fits) ? 48 : 32;
+    if (tile == 48 && wide_fits) return launch_feedback_tile<64, 48, 64, 4>(f, 1, st);
+    return launch_feedback_tile<32, 32, 32, 2>(f, 1, st);
+}
+}  // namespace
+
 extern "C" int crb_feedback_force(const crb_plan* p, const void* xs, const void* gain, const void* ref, void* u, void* stream) {
     if (int rc = need_device(p, "crb_feedback_force")) return rc;
     if (!xs || !gain || !u) return fail(CRB_EINVAL, "crb_feedback_force: null pointer");
@@ -935,17 +962,10 @@ extern "C" int crb_feedback_force(const crb_plan* p, const void* xs, const void*
     f.B = p->B; f.n = p->n_free; f.n2 = 2 * p->n_free;
     f.x_stride = size_t(2) * p->n_node * 4;
     f.u_stride = size_t(p->n_node) * 4;
-    // 64 x 64 tiles when they already give every CU >= 3 workgroups, else 32 x 32 (more, smaller groups)
-    const long tiles64 = long((p->B + 63) / 64) * ((p->n_free + 63) / 64);
+    hipStream_t fst = static_cast<hipStream_t>(stream);
     const char* force = std::getenv("CRB_FEEDBACK_TILE");
-    const bool big = force ? (std::atoi(force) == 64) : (tiles64 >= 768);
-    if (big) {
-        const dim3 grid((p->B + 63) / 64, (p->n_free + 63) / 64);
-        hipLaunchKernelGGL((crb_feedback_kernel<64, 64>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), f);
-    } else {
-        const dim3 grid((p->B + 31) / 32, (p->n_free + 31) / 32);
-        hipLaunchKernelGGL((crb_feedback_kernel<32, 32>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), f);
-    }
+    const int tile = force ? std::atoi(force) : 0;
+    if (int rc = launch_feedback(tile, f, fst)) return rc;
     HIP_TRY(hipGetLastError());
     return CRB_OK;
 }

@@ -425,12 +425,16 @@ def test_heterogeneous_ensemble_matches_per_beam_oracle(n_e, kind, kw):
         ensemble([base, nitinol_columns(n_e + 1, kind)], 2, kw)
 
 
-@pytest.mark.parametrize("n_e,B,bcs", [(4, 3, None), (24, 70, None), (128, 130, None),
+@pytest.mark.parametrize("tile", ["32", "48"])
+@pytest.mark.parametrize("n_e,B,bcs", [(4, 3, None), (24, 70, None), (128, 130, None), (50, 200, None),
                                         (7, 5, ["PINNED", "NONE", "NONE", "FIXED", "NONE", "NONE", "NONE"])])
-def test_fused_mfma_feedback_force_matches_matmul(n_e, B, bcs):
+def test_fused_mfma_feedback_force_matches_matmul(n_e, B, bcs, tile, monkeypatch):
     """crb_feedback_force (gather + fp64 MFMA GEMM + scatter) against (r - x) @ K^T in torch, with
-    asymmetric random data (an MFMA lane-map mistake cannot hide) and ragged tile edges."""
+    asymmetric random data (an MFMA lane-map mistake cannot hide) and ragged tile edges (rows, columns and
+    the K tail), for both tile shapes the dispatcher chooses between (32 x 32 and 64 x 48 outputs)."""
     import ctypes as C
+
+    monkeypatch.setenv("CRB_FEEDBACK_TILE", tile)
 
     from continuum_robot import _native as nat
 
