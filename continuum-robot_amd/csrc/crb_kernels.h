@@ -807,6 +807,48 @@ __device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
     }
 }
 
+// Reduction levels 1..LV-1 and the final block inverse of the lean kernels, given r after level 0.
+// Levels whose stride stays inside the workgroup's waves-per-beam interleave (l < LOGNW) go through LDS
+// columns + a barrier, the others are in-wave lane shifts.  A missing neighbour contributes through a
+// multiplier that is exactly 0, so whatever finite value the shift returns there is harmless.
+template <typename T, int LV, int LOGNW>
+__device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* ldsB, int t, int lane, int j, int S,
+                                                 bool valid, T r[3], T a[3]) {
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    T rlo[3], rhi[3];
+#pragma unroll
+    for (int l = 1; l < LV; ++l) {
+        if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
+            if (l == 1) CRB_SETPRIO(CRB_P_L1);
+            const int st = 1 << l;
+            T* buf = ldsB + size_t(l - 1) * 3 * (NT + 1);
+            buf[t] = r[0]; buf[(NT + 1) + t] = r[1]; buf[2 * (NT + 1) + t] = r[2];
+            __syncthreads();
+            const int tl = (valid && j - st >= 0) ? thread_of(j - st) : NULLT;
+            const int th = (valid && j + st < S) ? thread_of(j + st) : NULLT;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
+        } else {
+            if (l == LOGNW) CRB_SETPRIO(CRB_P_TAIL);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                switch (l - LOGNW) {
+                    case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
+                    case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
+                    case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
+                    case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
+                    case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
+                    default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
+                }
+            }
+        }
+        pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
+    }
+    CRB_SETPRIO(CRB_P_FIN);
+    pcr_apply_final<T>(cf.fin, r, a);
+}
+
 // EM (EM_*): the element kind when the whole topology has one; the force evaluation is then straight-line
 // code that the scheduler interleaves with the tail of the previous stage's reduction (measured +8 %
 // over the per-lane branch of EM_MIXED; a wave-uniform run-time branch does not get it).
@@ -1021,40 +1063,9 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             }
             pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
 
-            // -- remaining reduction levels (a missing neighbour contributes through a multiplier
-            //    that is exactly 0, so whatever finite value the shuffle returns there is harmless)
-#pragma unroll
-            for (int l = 1; l < LV; ++l) {
-                constexpr int dummy = 0; (void)dummy;
-                if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
-                    if (l == 1) CRB_SETPRIO(CRB_P_L1);
-                    const int st = 1 << l;
-                    T* buf = ldsB + size_t(l - 1) * 3 * (NT + 1);
-                    buf[t] = r[0]; buf[(NT + 1) + t] = r[1]; buf[2 * (NT + 1) + t] = r[2];
-                    __syncthreads();
-                    const int tl = (valid && j - st >= 0) ? thread_of(j - st) : NULLT;
-                    const int th = (valid && j + st < S) ? thread_of(j + st) : NULLT;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
-                } else {
-                    if (l == LOGNW) CRB_SETPRIO(CRB_P_TAIL);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        switch (l - LOGNW) {
-                            case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
-                            case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
-                            case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
-                            case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
-                            case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
-                            default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
-                        }
-                    }
-                }
-                pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
-            }
+            // -- remaining reduction levels and the final block inverse
             T a[3];
-            CRB_SETPRIO(CRB_P_FIN);
-            pcr_apply_final<T>(cf.fin, r, a);
+            lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
 
             // -- RK4 bookkeeping
 #pragma unroll
@@ -1080,6 +1091,188 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             p.x[xoff + c] = xq[c];
             p.x[xoff + plane + c] = xv[c];
         }
+    }
+}
+
+// ------------------------------------------------------------------ lean stage kernel
+// crb_stage_lean_kernel: ONE RK4 stage of the stage-split stepper (crb_rk4_stage: the input force changes per
+// stage, e.g. LQR feedback u = K(r - x) evaluated by crb_feedback_force) with the lean stepper's machinery:
+// register-resident multipliers, one merged exchange round {p, f_left} + level 0, in-wave levels by DPP.
+// A launch is one RHS per beam, so what the generic stage kernel pays most for is re-reading the solve
+// tables (440 B per node) for every beam: here a workgroup keeps them in registers and walks over several
+// beams (shared-table plans; per-beam tables reload).  The left neighbour's q (and the right neighbour's
+// rotation for gravity) are plain global loads of the stage state: no exchange round for them.
+//   k = f(t_stage, xs, u_stage + impulse);  acc = (stage ? acc : 0) + w k;
+//   stage < 3: out = x + c k;   stage 3: x += dt/6 acc           (same contract as MODE_STAGE)
+template <typename T>
+__host__ __device__ constexpr size_t stage_lean_lds_bytes(int NT, int lognw) {
+    return sizeof(T) * (size_t(NT + 1) * 6 * (lognw == 1 ? 2 : 1) + 3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
+}
+template <typename T, int LV, int LOGNW, bool GRAV, int EM>
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_stage_lean_kernel(const KParams<T> p) {
+    static_assert(LV >= 1, "lean stage kernel needs at least one reduction level");
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
+    T* const ldsA = reinterpret_cast<T*>(crb_smem);                         // [1 or 2][6][NT+1]: p0..2, fl0..2
+    T* const ldsB = ldsA + size_t(NT + 1) * 6 * (LOGNW == 1 ? 2 : 1);       // [level-1][3][NT+1]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int S = p.S;
+    const int j = (lane << LOGNW) | wave;
+    const bool valid = j < S;
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+    if (LOGNW > 0 && t == 0) {
+#pragma unroll
+        for (int k = 0; k < 6 * (LOGNW == 1 ? 2 : 1); ++k) ldsA[size_t(k) * (NT + 1) + NULLT] = T(0);
+#pragma unroll
+        for (int l = 1; l < LOGNW; ++l)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ldsB[(size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
+    }
+    const bool shared_tables = p.slot_stride == 0 && p.lv_stride == 0 && p.fin_stride == 0;
+    const bool corrected = (p.flags & 4u) != 0;
+    const bool has_right = valid && j + 1 < S, has_left = valid && j >= 1;
+    const size_t node = size_t(valid ? j + p.off : 0);
+    const size_t plane = size_t(p.n_node) * 4;
+    const T w = (p.stage == 0 || p.stage == 3) ? T(1) : T(2);
+    const T cs = (p.stage == 2) ? T(p.dt) : T(0.5 * p.dt);
+    const T dt6 = T(p.dt / 6.0);
+    const bool imp_on = p.t0 < p.duration;
+
+    ElemCoef<T> ec;
+    T dragc = T(0), hm_own = T(0), hm_left = T(0);
+    T mask[3] = {T(0), T(0), T(0)}, maskL[3] = {T(0), T(0), T(0)};
+    SolveCoef<T, LV> cf;
+    auto load_tables = [&](int beam) {
+        if (valid) {
+            const SlotConst<T>* st = p.slot + size_t(beam) * p.slot_stride;
+            const SlotConst<T>& sc = st[j];
+            ec = sc.elem;
+            dragc = (p.flags & 1u) ? sc.drag : T(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { mask[c] = sc.mask[c]; maskL[c] = has_left ? st[j - 1].mask[c] : T(0); }
+            if (GRAV) { hm_own = sc.half_mass; hm_left = has_left ? st[j - 1].half_mass : T(0); }
+#pragma unroll
+            for (int l = 0; l < LV; ++l) {
+                const T* src = p.pcr_levels + size_t(beam) * p.lv_stride + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(beam) * p.fin_stride + size_t(j) * PCR_FINAL_VALS + k];
+        } else {
+            ec.kind = KIND_NONE;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ec.c[k] = T(0);
+#pragma unroll
+            for (int l = 0; l < LV; ++l)
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
+        }
+    };
+    if (shared_tables) load_tables(0);
+
+    int it = 0;
+    for (int beam = blockIdx.x; beam < p.B; beam += gridDim.x, ++it) {
+        if (!shared_tables) load_tables(beam);
+        // ---- this stage's state, the neighbours' pieces of it, the input force
+        const size_t xoff = size_t(beam) * 2 * plane + node * 4;
+        T sq[3] = {T(0), T(0), T(0)}, sv[3] = {T(0), T(0), T(0)}, qL[3] = {T(0), T(0), T(0)}, uin[3] = {T(0), T(0), T(0)};
+        T x0q[3] = {T(0), T(0), T(0)}, x0v[3] = {T(0), T(0), T(0)}, aq[3] = {T(0), T(0), T(0)}, av[3] = {T(0), T(0), T(0)};
+        T phiR = T(0), amp = T(0);
+        typedef T rec4 __attribute__((ext_vector_type(4)));
+        if (valid) {
+            // a node record is 4 values = one aligned 32-byte (fp64) / 16-byte (fp32) vector: whole-record
+            // loads instead of three scalar ones (the slots of a wave are every NW-th node, so scalar loads
+            // would pull each 128-byte line through L1 once per component: measured 31.7 -> 24 us)
+            auto ldrec = [](const T* ptr) { return *reinterpret_cast<const rec4*>(ptr); };
+            const rec4 rq = ldrec(p.xs + xoff), rv = ldrec(p.xs + xoff + plane);
+            const rec4 bq = ldrec(p.x + xoff), bv = ldrec(p.x + xoff + plane);
+            rec4 rl = rec4{T(0), T(0), T(0), T(0)}, cq = rl, cv = rl, ru = rl;
+            if (has_left) rl = ldrec(p.xs + xoff - 4);
+            if (p.stage > 0) { cq = ldrec(p.acc + xoff); cv = ldrec(p.acc + xoff + plane); }
+            if (p.u_held) ru = ldrec(p.u_held + size_t(beam) * plane + node * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sq[c] = rq[c] * mask[c];
+                sv[c] = rv[c] * mask[c];
+                qL[c] = rl[c] * maskL[c];
+                x0q[c] = bq[c] * mask[c];
+                x0v[c] = bv[c] * mask[c];
+                aq[c] = cq[c];
+                av[c] = cv[c];
+                uin[c] = ru[c];
+            }
+            if (GRAV && has_right) phiR = p.xs[xoff + 4 + 2];
+            if (p.amp && j == p.imp_slot) amp = p.amp[beam];
+        }
+        // ---- forces on this node from its own element, drag, gravity, inputs
+        T fl[3], fr[3];
+        CRB_SETPRIO(CRB_P_FORCE);
+        if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
+        else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
+        else elem_force<T>(ec, qL, sq, corrected, fl, fr);
+        CRB_SETPRIO(CRB_P_XCHG);
+        T pp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pp[c] = uin[c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];
+        pp[1] += drag_force<T>(dragc, sv[1]);
+        if (GRAV) {
+            T g_own[2], g_left[2];
+            gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
+            gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+            pp[0] += g_own[0] + g_left[0];
+            pp[1] += g_own[1] + g_left[1];
+        }
+        // ---- round A: publish {p, fl}, rebuild r of this node and of both stride-1 neighbours, level 0
+        T r[3], rlo[3], rhi[3];
+        if (LOGNW == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+                r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+                rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+            }
+        } else {
+            T* bufA = ldsA + ((LOGNW == 1 && (it & 1)) ? size_t(NT + 1) * 6 : 0);
+            auto col = [&](int k, int th) -> T& { return bufA[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { col(c, t) = pp[c]; col(3 + c, t) = fl[c]; }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rlo[c] = col(c, t_l1) - fl[c];
+                r[c] = pp[c] - col(3 + c, t_r1);
+                rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+            }
+        }
+        pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+        T a[3];
+        lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
+        // ---- RK4 bookkeeping of this stage
+        if (valid) {
+            auto strec = [](T* ptr, const T v[3]) { *reinterpret_cast<rec4*>(ptr) = rec4{v[0], v[1], v[2], T(0)}; };
+            T nq[3], nv[3], oq[3], ov[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                nq[c] = (p.stage ? aq[c] : T(0)) + w * sv[c];
+                nv[c] = (p.stage ? av[c] : T(0)) + w * a[c];
+                oq[c] = (p.stage < 3) ? x0q[c] + cs * sv[c] : x0q[c] + dt6 * nq[c];
+                ov[c] = (p.stage < 3) ? x0v[c] + cs * a[c] : x0v[c] + dt6 * nv[c];
+            }
+            if (p.stage < 3) {   // (whole records: the pad value is written as 0)
+                strec(p.out + xoff, oq); strec(p.out + xoff + plane, ov);
+                strec(p.acc + xoff, nq); strec(p.acc + xoff + plane, nv);
+            } else {
+                strec(p.x + xoff, oq); strec(p.x + xoff + plane, ov);
+            }
+        }
+        // LOGNW >= 2: the level-1 barrier above orders this beam's round-A reads before the next beam's
+        // round-A writes; LOGNW == 1 alternates two round-A buffers; LOGNW == 0 uses no LDS
     }
 }
 

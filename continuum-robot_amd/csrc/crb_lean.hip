@@ -21,31 +21,46 @@ hipError_t one(const KParams<T>& k, int n_beams, hipStream_t st) {
     hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM>), grid, block, smem, st, k);
     return hipGetLastError();
 }
-template <int LV, int LOGNW, bool GRAV>
-hipError_t by_em(const KParams<T>& k, int n_beams, int em, hipStream_t st) {
+template <int LV, int LOGNW, bool GRAV, int EM>
+hipError_t one_stage(const KParams<T>& k, int n_groups, hipStream_t st) {
+    const dim3 grid(n_groups), block(64 << LOGNW);
+    const size_t smem = stage_lean_lds_bytes<T>(64 << LOGNW, LOGNW);
+    hipLaunchKernelGGL((crb_stage_lean_kernel<T, LV, LOGNW, GRAV, EM>), grid, block, smem, st, k);
+    return hipGetLastError();
+}
+// STAGE selects the kernel family: the fused multi-step stepper or the one-stage kernel
+template <int LV, int LOGNW, bool GRAV, bool STAGE>
+hipError_t by_em(const KParams<T>& k, int n, int em, hipStream_t st) {
+    if (STAGE) {
+        switch (em) {
+            case EM_LINEAR: return one_stage<LV, LOGNW, GRAV, EM_LINEAR>(k, n, st);
+            case EM_NONLINEAR: return one_stage<LV, LOGNW, GRAV, EM_NONLINEAR>(k, n, st);
+            default: return one_stage<LV, LOGNW, GRAV, EM_MIXED>(k, n, st);
+        }
+    }
     switch (em) {
-        case EM_LINEAR: return one<LV, LOGNW, GRAV, EM_LINEAR>(k, n_beams, st);
-        case EM_NONLINEAR: return one<LV, LOGNW, GRAV, EM_NONLINEAR>(k, n_beams, st);
-        default: return one<LV, LOGNW, GRAV, EM_MIXED>(k, n_beams, st);
+        case EM_LINEAR: return one<LV, LOGNW, GRAV, EM_LINEAR>(k, n, st);
+        case EM_NONLINEAR: return one<LV, LOGNW, GRAV, EM_NONLINEAR>(k, n, st);
+        default: return one<LV, LOGNW, GRAV, EM_MIXED>(k, n, st);
     }
 }
-template <int LV, bool GRAV>
-hipError_t by_nw(const KParams<T>& k, int n_beams, int lognw, int em, hipStream_t st) {
+template <int LV, bool GRAV, bool STAGE>
+hipError_t by_nw(const KParams<T>& k, int n, int lognw, int em, hipStream_t st) {
     switch (lognw) {
-        case 0: return by_em<LV, 0, GRAV>(k, n_beams, em, st);
-        case 1: return by_em<LV, 1, GRAV>(k, n_beams, em, st);
-        case 2: return by_em<LV, 2, GRAV>(k, n_beams, em, st);
-        case 3: return by_em<LV, 3, GRAV>(k, n_beams, em, st);
+        case 0: return by_em<LV, 0, GRAV, STAGE>(k, n, em, st);
+        case 1: return by_em<LV, 1, GRAV, STAGE>(k, n, em, st);
+        case 2: return by_em<LV, 2, GRAV, STAGE>(k, n, em, st);
+        case 3: return by_em<LV, 3, GRAV, STAGE>(k, n, em, st);
         default: return hipErrorInvalidValue;
     }
 }
-template <bool GRAV>
-hipError_t by_lv(const KParams<T>& k, int n_beams, int levels, int lognw, int em, hipStream_t st) {
+template <bool GRAV, bool STAGE>
+hipError_t by_lv(const KParams<T>& k, int n, int levels, int lognw, int em, hipStream_t st) {
     switch (levels) {
-        case 3: return by_nw<3, GRAV>(k, n_beams, lognw, em, st);
-        case 4: return by_nw<4, GRAV>(k, n_beams, lognw, em, st);
-        case 5: return by_nw<5, GRAV>(k, n_beams, lognw, em, st);
-        case 6: return by_nw<6, GRAV>(k, n_beams, lognw, em, st);
+        case 3: return by_nw<3, GRAV, STAGE>(k, n, lognw, em, st);
+        case 4: return by_nw<4, GRAV, STAGE>(k, n, lognw, em, st);
+        case 5: return by_nw<5, GRAV, STAGE>(k, n, lognw, em, st);
+        case 6: return by_nw<6, GRAV, STAGE>(k, n, lognw, em, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -57,7 +72,19 @@ hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, 
         return one<5, 2, false, EM_NONLINEAR>(k, n_beams, st);
     return hipErrorInvalidValue;
 #else
-    return grav ? by_lv<true>(k, n_beams, levels, lognw, elem_mode, st) : by_lv<false>(k, n_beams, levels, lognw, elem_mode, st);
+    return grav ? by_lv<true, false>(k, n_beams, levels, lognw, elem_mode, st)
+                : by_lv<false, false>(k, n_beams, levels, lognw, elem_mode, st);
+#endif
+}
+
+hipError_t launch_stage_lean(const KParams<T>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st) {
+#ifdef CRB_FAST_BUILD  // kernel-tuning build: the config-5 instance (128 linear elements + gravity, fp64)
+    if (sizeof(T) == 8 && levels == 5 && lognw == 1 && grav && elem_mode == EM_LINEAR)
+        return one_stage<5, 1, true, EM_LINEAR>(k, n_groups, st);
+    return hipErrorInvalidValue;
+#else
+    return grav ? by_lv<true, true>(k, n_groups, levels, lognw, elem_mode, st)
+                : by_lv<false, true>(k, n_groups, levels, lognw, elem_mode, st);
 #endif
 }
 }  // namespace crb

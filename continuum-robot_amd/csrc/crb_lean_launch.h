@@ -10,4 +10,8 @@ namespace crb {
 // levels in 3..6, lognw in 0..3 (callers check eligibility); hipErrorInvalidValue otherwise.
 hipError_t launch_lean(const KParams<double>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
 hipError_t launch_lean(const KParams<float>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
+// launches crb_stage_lean_kernel<T, levels, lognw, grav, elem_mode> on `n_groups` workgroups (each walks
+// over beams blockIdx.x, blockIdx.x + n_groups, ...)
+hipError_t launch_stage_lean(const KParams<double>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
+hipError_t launch_stage_lean(const KParams<float>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
 }  // namespace crb

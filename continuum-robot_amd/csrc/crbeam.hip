@@ -685,6 +685,33 @@ int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     return CRB_OK;
 }
 
+// One RK4 stage through the lean machinery (crb_stage_lean_kernel): same eligibility as the lean stepper,
+// except that a per-node input force is part of the stage contract.  Shared-table plans run a bounded
+// number of workgroups, each walking over several beams with the solve tables in registers.
+inline bool stage_lean_eligible(const crb_plan* p) {
+    return lean_eligible(p, nullptr) && std::getenv("CRB_DISABLE_LEAN_STAGE") == nullptr;
+}
+template <typename T>
+int launch_stage_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    const bool shared = p->slot_stride == 0 && p->lv_stride == 0 && p->fin_stride == 0;
+    int groups = p->B;
+    if (shared) {
+        // one wave per SIMD (256 CUs x 4) / waves per group: measured best at 2048 x 128 (208 us per step
+        // against 220 with two waves per SIMD and 236 with one group per beam) -- the table reload per
+        // group costs more than the extra latency hiding gains
+        const int resident = 256 * 4 / (1 << p->lognw);
+        const char* env = std::getenv("CRB_STAGE_GROUPS");
+        const int cap = env ? std::atoi(env) : resident;
+        if (cap > 0 && groups > cap) groups = cap;
+    }
+#ifdef CRB_FAST_BUILD
+    if constexpr (sizeof(T) == 4) return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: fp32 lean stage kernel not built");
+    else
+#endif
+    HIP_TRY(crb::launch_stage_lean(k, groups, p->levels, p->lognw, (p->flags & CRB_FORCE_GRAVITY) != 0, p->elem_mode, st));
+    return CRB_OK;
+}
+
 template <typename T>
 int pack_impl(const crb_plan* p, bool pack, int rows, const void* red_in, void* dev, void* red_out, hipStream_t st) {
     const size_t total = size_t(p->B) * rows * p->n_free;
@@ -994,6 +1021,7 @@ extern "C" int crb_rk4_stage(const crb_plan* p, void* x, const void* xs, void* a
         k.amp = static_cast<const double*>(amp);
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
         k.stage = stage; k.t0 = t_stage; k.dt = dt;
+        if (stage_lean_eligible(p)) return launch_stage_lean<double>(p, k, st);
         return launch_beam<double, MODE_STAGE>(p, k, st);
     }
     KParams<float> k = base_params<float>(p);
@@ -1002,6 +1030,7 @@ extern "C" int crb_rk4_stage(const crb_plan* p, void* x, const void* xs, void* a
     k.amp = static_cast<const float*>(amp);
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
     k.stage = stage; k.t0 = t_stage; k.dt = dt;
+    if (stage_lean_eligible(p)) return launch_stage_lean<float>(p, k, st);
     return launch_beam<float, MODE_STAGE>(p, k, st);
 }
 
