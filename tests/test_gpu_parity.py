@@ -360,6 +360,44 @@ def test_lqr_feedback_rollout_matches_reference(golden, name):
         assert rel_err(got[b], want) < 1e-9
 
 
+@pytest.mark.parametrize("n_e,kind,kw,hetero", [
+    (64, "linear", dict(enable_gravity=True), False),                               # one wave per beam, gravity
+    (128, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), False),        # two waves (config 5's shape)
+    (128, "linear", dict(enable_gravity=True), True),                                # per-beam tables: reload per beam
+    (200, "mixed", dict(fluid_density=1000.0, enable_fluid=True), False),            # four waves, padding threads
+    (300, "linear", dict(), False),                                                  # eight waves
+])
+def test_lean_stage_kernel_feedback_rollout_matches_oracle(n_e, kind, kw, hetero, monkeypatch):
+    """The stage-split stepper (crb_feedback_force + crb_rk4_stage) on beams long enough for the lean stage
+    kernel (crb_stage_lean_kernel), with fewer workgroups than beams so that each walks over several beams
+    (uneven split), a dense random gain, per-beam references and amplitudes, from a random state."""
+    monkeypatch.setenv("CRB_STAGE_GROUPS", "2")
+    rng = np.random.default_rng(n_e)
+    kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)] if kind == "mixed" else kind
+    base = nitinol_columns(n_e, kinds)
+    B = 5
+    per_beam = [_scaled(base, rng) for _ in range(B)] if hetero else [base] * B
+    ens = ensemble(per_beam if hetero else base, B, kw)
+    n = ens.n
+    gain = rng.normal(0.0, 2e-2, (n, 2 * n))   # (small: the rotational DOFs have tiny inertia, RK4 must stay stable)
+    ref = rng.normal(0.0, 1e-4, (B, 2 * n))
+    x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
+    amps = 0.05 * (1.0 + np.arange(B))
+    ens.set_state(x0)
+    steps, dt = 40, 2e-5
+    ens.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    for b in range(B):
+        want = oracle_beam(per_beam[b], **kw).rk4_feedback(x0[b], dt, steps, gain, reference=ref[b], amp=amps[b])
+        assert rel_err(got[b], want) < 1e-9, b
+    # the generic stage kernel gives the same answer
+    monkeypatch.setenv("CRB_DISABLE_LEAN_STAGE", "1")
+    ens2 = ensemble(per_beam if hetero else base, B, kw)
+    ens2.set_state(x0)
+    ens2.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps)
+    assert rel_err(ens2.unpack_state().cpu().numpy(), got) < 1e-11
+
+
 @pytest.mark.parametrize("lean", [True, False])
 def test_strided_recording_matches_chunked_stepping(lean):
     """f-4: on-device t_eval-style recording of the tip displacement / velocity."""
