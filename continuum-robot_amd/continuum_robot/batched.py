@@ -300,9 +300,19 @@ class BeamEnsemble:
             desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, full // 3, full % 3
             desc.duration = float(impulse_duration)
             desc.amp = amp.data_ptr()
+        t, dt = self.time, float(dt)
+        if fused:   # the whole loop is one native call (crb_step_rk4_feedback issues every launch)
+            work = torch.empty((int(self._lib.crb_feedback_work_bytes(self.plan.h)),), dtype=torch.uint8, device=self.device)
+            t_end = C.c_double(0.0)
+            with torch.cuda.device(self.device):
+                nat.check(self._lib.crb_step_rk4_feedback(self.plan.h, self._ptr(self.state), t, dt, int(n_steps), self._ptr(K),
+                                                          self._ptr(ref), C.byref(desc), self._ptr(work), C.byref(t_end),
+                                                          self._stream()))
+            self._keep = [amp, K, ref, work]
+            self.time = float(t_end.value)
+            return self.time
         acc = torch.empty_like(self.state)
         bufs = (torch.empty_like(self.state), torch.empty_like(self.state))
-        t, dt = self.time, float(dt)
         with torch.cuda.device(self.device):
             stream = self._stream()
             for _ in range(int(n_steps)):

@@ -860,6 +860,43 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     return launch_beam<float, MODE_STEP>(p, k, st);
 }
 
+extern "C" size_t crb_feedback_work_bytes(const crb_plan* p) {
+    if (!p) return 0;
+    const size_t state = size_t(p->B) * 2 * p->n_node * 4 * sizeof(double), force = state / 2;
+    return 3 * state + force;
+}
+
+extern "C" int crb_step_rk4_feedback(const crb_plan* p, void* x, double t0, double dt, int n_steps, const void* gain,
+                                     const void* ref, const crb_input_desc* in, void* work, double* t_end, void* stream) {
+    if (int rc = need_device(p, "crb_step_rk4_feedback")) return rc;
+    if (!x || !gain || !work) return fail(CRB_EINVAL, "crb_step_rk4_feedback: null pointer");
+    if (p->dtype != CRB_F64) return fail(CRB_EUNSUPPORTED, "crb_step_rk4_feedback: fp64 plans only");
+    if (n_steps < 0 || !(dt > 0)) return fail(CRB_EINVAL, "crb_step_rk4_feedback: n_steps >= 0 and dt > 0 required");
+    const size_t state = size_t(p->B) * 2 * p->n_node * 4 * sizeof(double);
+    char* w = static_cast<char*>(work);
+    void* acc = w;
+    void* bufs[2] = {w + state, w + 2 * state};
+    void* u = w + 3 * state;
+    // entries of u outside the free DOFs are never written by the GEMM and must read as zero
+    HIP_TRY(hipMemsetAsync(u, 0, state / 2, static_cast<hipStream_t>(stream)));
+    double t = t0;
+    for (int s = 0; s < n_steps; ++s) {
+        // same clock convention as crb_step_rk4: stage times t, t + dt/2, t + dt/2, t + dt; t accumulates
+        const double th = t + 0.5 * dt, t1 = t + dt;
+        const double ts[4] = {t, th, th, t1};
+        const void* cur = x;
+        for (int stage = 0; stage < 4; ++stage) {
+            if (int rc = crb_feedback_force(p, cur, gain, ref, u, stream)) return rc;
+            void* nxt = bufs[stage & 1];
+            if (int rc = crb_rk4_stage(p, x, cur, acc, nxt, u, stage, ts[stage], dt, in, stream)) return rc;
+            cur = nxt;
+        }
+        t = t1;
+    }
+    if (t_end) *t_end = t;
+    return CRB_OK;
+}
+
 namespace {
 template <typename T, int LV>
 int launch_rk45_lv(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hipStream_t st) {

@@ -206,6 +206,14 @@ int crb_feedback_force(const crb_plan* plan, const void* xs, const void* gain, c
 int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage,
                   int stage, double t_stage, double dt, const crb_input_desc* input, void* stream);
 
+/* The closed loop of examples/lqr_control.py:95-125 as ONE call: n_steps RK4 steps with u = K (r - x)
+ * re-evaluated at every stage (crb_feedback_force, then crb_rk4_stage), all launches issued from here
+ * (fp64 plans).  work: device scratch of crb_feedback_work_bytes(plan) bytes (three state-sized buffers and
+ * one force-sized buffer; contents need not be initialised).  Returns the accumulated clock in *t_end. */
+size_t crb_feedback_work_bytes(const crb_plan* plan);
+int crb_step_rk4_feedback(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const void* gain,
+                          const void* ref, const crb_input_desc* input, void* work, double* t_end, void* stream);
+
 /* crb_step_rk4 plus strided recording of one DOF (rec may be NULL). */
 int crb_step_rk4_rec(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const crb_input_desc* input,
                      const crb_record_desc* rec, double* t_end, void* stream);
