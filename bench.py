@@ -284,7 +284,7 @@ def main():
                        "plan_ms": plan_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("crb_beam_kernel<MODE_STAGE> + crb_feedback_kernel" if gain is not None
+                         "kernel": ("crb_stage_lean_kernel + crb_feedback_kernel" if gain is not None
                                     else "crb_step_lean_kernel"),
                          "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,

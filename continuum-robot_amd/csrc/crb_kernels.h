@@ -995,7 +995,12 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             if (GRAV) {
                 T g_own[2], g_left[2];
                 gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
-                gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+                if (LOGNW == 0) {  // segment j-1 IS the left lane's own segment: take its result (bit-identical), one sincos less
+                    g_left[0] = lane_lower<T, 1>(g_own[0], lane);
+                    g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+                } else {
+                    gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+                }
                 pp[0] += g_own[0] + g_left[0];
                 pp[1] += g_own[1] + g_left[1];
             }
@@ -1224,7 +1229,12 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         if (GRAV) {
             T g_own[2], g_left[2];
             gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
-            gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+            if (LOGNW == 0) {  // (as in the stepper: the left lane's own segment)
+                g_left[0] = lane_lower<T, 1>(g_own[0], lane);
+                g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+            } else {
+                gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+            }
             pp[0] += g_own[0] + g_left[0];
             pp[1] += g_own[1] + g_left[1];
         }
