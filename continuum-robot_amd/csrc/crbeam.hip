@@ -1000,14 +1000,27 @@ int launch_feedback_tile(const FeedbackParams& f, int ksplit, hipStream_t st) {
     }
     return CRB_OK;
 }
-// tile: 0 = choose.  64 x 48 (BK 64) gives the config-5 shape one workgroup per CU and the fewest L2
-// reads (33 us at 2048 x 768 x 384 against 37 us for 32 x 32); small ensembles take 32 x 32 for the
-// larger grid.  CRB_FEEDBACK_TILE=48|32 forces one (tests cover both).
+template <int BN, int BK>
+int launch_feedback_ws(const FeedbackParams& f, hipStream_t st) {
+    const dim3 grid((f.B + 63) / 64, (f.n + BN - 1) / BN);
+    const size_t smem = feedback_lds_bytes<64, BN, BK>(f.n2);
+    if (f.ref) {
+        if (int rc = allow_lds(crb_feedback_ws_kernel<BN, BK, true>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_ws_kernel<BN, BK, true>), grid, dim3(512), smem, st, f);
+    } else {
+        if (int rc = allow_lds(crb_feedback_ws_kernel<BN, BK, false>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_ws_kernel<BN, BK, false>), grid, dim3(512), smem, st, f);
+    }
+    return CRB_OK;
+}
+// tile: 0 = choose.  Large ensembles: 64 x 48 outputs per workgroup, wave-specialised (one workgroup per CU
+// and the fewest L2 reads at the config-5 shape: 32.7 us at 2048 x 768 x 384 against 37 us for 32 x 32);
+// small ensembles: 32 x 32 for the larger grid.  CRB_FEEDBACK_TILE=48|32 forces one (tests cover both).
 int launch_feedback(int tile, const FeedbackParams& f, hipStream_t st) {
     const long wide_groups = long((f.B + 63) / 64) * ((f.n + 47) / 48);
     const bool wide_fits = feedback_lds_bytes<64, 48, 64>(f.n2) <= size_t(160) * 1024;
     if (tile == 0) tile = (wide_groups >= 192 && wide_fits) ? 48 : 32;
-    if (tile == 48 && wide_fits) return launch_feedback_tile<64, 48, 64, 4>(f, 1, st);
+    if (tile == 48 && wide_fits) return launch_feedback_ws<48, 64>(f, st);
     return launch_feedback_tile<32, 32, 32, 2>(f, 1, st);
 }
 }  // namespace
