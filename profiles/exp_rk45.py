@@ -1,0 +1,24 @@
+"""measurement helper: crb_solve_rk45 (adaptive Dormand-Prince, per-beam step control, one launch) at the
+config-3 shape; prints RHS evaluations per second next to the fixed-step stepper's."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "continuum-robot_amd")]
+import numpy as np, torch
+from continuum_robot.batched import BeamEnsemble
+from continuum_robot.models.force_params import ForceParams
+from tests.helpers import nitinol_columns
+
+B, ne = 4096, 256
+cols = nitinol_columns(ne, "nonlinear")
+fp = ForceParams(fluid_density=1000.0, enable_fluid_effects=True, enable_gravity_effects=False)
+ens = BeamEnsemble(cols, B, force_params=fp)
+amps = 0.05 * (1.0 + np.arange(B) / B)
+for rtol, atol in ((1e-3, 1e-6), (1e-6, 1e-9)):
+    ens.zero_state()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    st = ens.solve_rk45(2e-3, rtol=rtol, atol=atol, impulse_amp=amps, t0=0.0)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    nfev = np.asarray(st["nfev"], dtype=np.float64)
+    acc = np.asarray(st["accepted"], dtype=np.float64)
+    print(f"rtol {rtol:g}: {dt*1e3:.1f} ms, accepted steps {acc.min():.0f}..{acc.max():.0f}, nfev mean {nfev.mean():.0f}, "
+          f"{nfev.sum()*ne/dt:.3e} element-RHS/s (lean RK4 stepper: 4 RHS per step)")

@@ -596,3 +596,53 @@ def test_new_entry_points_reject_bad_arguments():
         ens.step(10, 2e-5, record=(999, "w"))
     with pytest.raises(ValueError, match="n_beams entries"):
         ensemble([nitinol_columns(8, "linear")], 2)
+
+
+def test_native_feedback_rollout_entry_point_contract():
+    """crb_step_rk4_feedback: argument checks, the accumulated clock it returns, and equality with the same
+    loop issued stage by stage through crb_feedback_force + crb_rk4_stage."""
+    import ctypes as C
+
+    from continuum_robot import _native as nat
+
+    lib = nat.load()
+    cols = nitinol_columns(70, "linear")
+    B, dt, steps = 3, 2e-5, 7
+    rng = np.random.default_rng(3)
+    ens = ensemble(cols, B, dict(enable_gravity=True))
+    n = ens.n
+    gain = torch.tensor(rng.normal(0.0, 2e-2, (n, 2 * n)), device=ens.device)
+    x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
+    ens.set_state(x0)
+    work = torch.empty((int(lib.crb_feedback_work_bytes(ens.plan.h)),), dtype=torch.uint8, device=ens.device)
+    assert work.numel() == 3 * ens.state.numel() * 8 + ens.state.numel() * 4
+    t_end = C.c_double(-1.0)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    # bad arguments
+    assert lib.crb_step_rk4_feedback(ens.plan.h, vp(ens.state), 0.0, dt, steps, None, None, None, vp(work), C.byref(t_end), None) != 0
+    assert b"null pointer" in lib.crb_last_error()
+    assert lib.crb_step_rk4_feedback(ens.plan.h, vp(ens.state), 0.0, -1.0, steps, vp(gain), None, None, vp(work), C.byref(t_end), None) != 0
+    f32 = ensemble(cols, B, dict(enable_gravity=True), dtype=torch.float32)
+    assert lib.crb_step_rk4_feedback(f32.plan.h, vp(f32.state), 0.0, dt, 1, vp(gain), None, None, vp(work), C.byref(t_end), None) != 0
+    assert b"fp64 plans only" in lib.crb_last_error()
+    # the rollout, against the stage-by-stage loop
+    nat.check(lib.crb_step_rk4_feedback(ens.plan.h, vp(ens.state), 0.25, dt, steps, vp(gain), None, None, vp(work),
+                                        C.byref(t_end), None))
+    t = 0.25
+    for _ in range(steps):
+        t = t + dt
+    assert t_end.value == t
+    ref = ensemble(cols, B, dict(enable_gravity=True))
+    ref.set_state(x0)
+    acc, bufs = torch.empty_like(ref.state), (torch.empty_like(ref.state), torch.empty_like(ref.state))
+    u = torch.zeros((B, ref.n_node, 4), dtype=torch.float64, device=ref.device)
+    t = 0.25
+    for _ in range(steps):
+        cur = ref.state
+        for s, ts in enumerate((t, t + 0.5 * dt, t + 0.5 * dt, t + dt)):
+            nat.check(lib.crb_feedback_force(ref.plan.h, vp(cur), vp(gain), None, vp(u), None))
+            nat.check(lib.crb_rk4_stage(ref.plan.h, vp(ref.state), vp(cur), vp(acc), vp(bufs[s & 1]), vp(u), s, ts, dt, None, None))
+            cur = bufs[s & 1]
+        t = t + dt
+    torch.cuda.synchronize()
+    assert torch.equal(ens.state, ref.state)
