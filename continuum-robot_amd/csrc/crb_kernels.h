@@ -457,7 +457,15 @@ __device__ __forceinline__ double block_sum(double v, double* red, int NT, int t
     return v;
 }
 
-template <typename T, int LV, int MAXT, int MINW>
+// (defined with the lean kernels below) one RHS through the lean machinery: q exchange, element force, merged
+// exchange round + level 0, in-wave levels -- for plans without gravity
+template <typename T, int LV, int LOGNW, int EM>
+__device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool corrected, const SolveCoef<T, LV>& cf, T* lds3, int t,
+                                         int lane, int j, int S, bool valid, const T sq[3], const T sv[3], const T uadd[3], T a[3]);
+
+// LNW < 0: the general RHS (stage_accel: any gravity table, any waves-per-beam count, run-time topology).
+// LNW = 0..2: the lean RHS with 2^LNW waves per beam and element mode EM (plans without gravity).
+template <typename T, int LV, int MAXT, int MINW, int LNW = -1, int EM = 0>
 __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p, const Rk45Params q) {
     const int NT = blockDim.x;
     const Lds<T> lds = carve_lds<T>(NT);
@@ -524,13 +532,23 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
         }
         if (p.amp && tp.j == p.imp_slot) amp = p.amp[beam];
     }
+    // lean RHS: the 14*NT values in front of Ks hold its exchange columns ([3 + 6 + 3][NT + 1] incl. the zero
+    // "no neighbour" entries)
+    const int lj = (tp.lane << (LNW > 0 ? LNW : 0)) | (LNW > 0 ? (t >> 6) : 0);
+    const bool corrected = (p.flags & 4u) != 0;
+    const T dragc = (p.flags & 1u) ? sc.drag : T(0);
+    if (LNW >= 0) {
+        if (t < 12) lds.q[size_t(t) * (NT + 1) + NT] = T(0);
+        __syncthreads();
+    }
     // f(ts, state) -> derivative d[6] = [v ; a]
     auto deriv = [&](double ts, const T st[6], T d[6]) {
         const T av = (ts < p.duration) ? amp : T(0);
         T uadd[3], a[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) uadd[c] = uh[c] + ((c == p.imp_dof) ? av : T(0));
-        stage_accel<T, LV, false, false>(p, lds, sc, cf, tp, st, st + 3, uadd, a);
+        if (LNW >= 0) lean_rhs<T, LV, (LNW >= 0 ? LNW : 0), EM>(sc.elem, dragc, corrected, cf, lds.q, t, tp.lane, lj, p.S, valid, st, st + 3, uadd, a);
+        else stage_accel<T, LV, false, false>(p, lds, sc, cf, tp, st, st + 3, uadd, a);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { d[c] = st[3 + c]; d[3 + c] = a[c]; }
     };
@@ -847,6 +865,63 @@ __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* 
     }
     CRB_SETPRIO(CRB_P_FIN);
     pcr_apply_final<T>(cf.fin, r, a);
+}
+
+template <typename T, int LV, int LOGNW, int EM>
+__device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool corrected, const SolveCoef<T, LV>& cf, T* lds3, int t,
+                                         int lane, int j, int S, bool valid, const T sq[3], const T sv[3], const T uadd[3], T a[3]) {
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    T* const ldsQ = lds3;                           // [3][NT+1]  stage positions
+    T* const ldsA = lds3 + 3 * size_t(NT + 1);      // [6][NT+1]  p0..2, fl0..2
+    T* const ldsB = lds3 + 9 * size_t(NT + 1);      // [LOGNW-1][3][NT+1]
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+    // -- the left neighbour's position (its own exchange: stage states are arbitrary combinations here)
+    T qL[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(sq[c], lane);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ldsQ[size_t(c) * (NT + 1) + t] = sq[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = ldsQ[size_t(c) * (NT + 1) + t_l1];
+    }
+    T fl[3], fr[3];
+    if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
+    else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
+    else elem_force<T>(ec, qL, sq, corrected, fl, fr);
+    T pp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pp[c] = uadd[c] - fr[c];
+    pp[1] += drag_force<T>(dragc, sv[1]);
+    // -- merged exchange round {p, fl} + level 0.  The barrier of the q exchange above orders the previous
+    //    call's reads of these columns before this call's writes (and vice versa for the q columns).
+    T r[3], rlo[3], rhi[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+            r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+            rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+        }
+    } else {
+        auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { col(c, t) = pp[c]; col(3 + c, t) = fl[c]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rlo[c] = col(c, t_l1) - fl[c];
+            r[c] = pp[c] - col(3 + c, t_r1);
+            rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+        }
+    }
+    pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+    lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
 }
 
 // EM (EM_*): the element kind when the whole topology has one; the force evaluation is then straight-line

@@ -64,7 +64,50 @@ hipError_t by_lv(const KParams<T>& k, int n, int levels, int lognw, int em, hipS
         default: return hipErrorInvalidValue;
     }
 }
+template <int LV, int LNW, int EM>
+hipError_t one_rk45(const KParams<T>& k, const Rk45Params& q, int n_beams, hipStream_t st) {
+    constexpr int NT = 64 << LNW;
+    const size_t smem = rk45_lds_bytes<T>(NT);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_rk45_kernel<T, LV, 256, 1, LNW, EM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((crb_rk45_kernel<T, LV, 256, 1, LNW, EM>), dim3(n_beams), dim3(NT), smem, st, k, q);
+    return hipGetLastError();
+}
+template <int LV, int LNW>
+hipError_t rk45_by_em(const KParams<T>& k, const Rk45Params& q, int n, int em, hipStream_t st) {
+    switch (em) {
+        case EM_LINEAR: return one_rk45<LV, LNW, EM_LINEAR>(k, q, n, st);
+        case EM_NONLINEAR: return one_rk45<LV, LNW, EM_NONLINEAR>(k, q, n, st);
+        default: return one_rk45<LV, LNW, EM_MIXED>(k, q, n, st);
+    }
+}
+template <int LV>
+hipError_t rk45_by_nw(const KParams<T>& k, const Rk45Params& q, int n, int lognw, int em, hipStream_t st) {
+    switch (lognw) {
+        case 0: return rk45_by_em<LV, 0>(k, q, n, em, st);
+        case 1: return rk45_by_em<LV, 1>(k, q, n, em, st);
+        case 2: return rk45_by_em<LV, 2>(k, q, n, em, st);
+        default: return hipErrorInvalidValue;
+    }
+}
 }  // namespace
+
+hipError_t launch_rk45_lean(const KParams<T>& k, const Rk45Params& q, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    return hipErrorInvalidValue;
+#else
+    switch (levels) {
+        case 3: return rk45_by_nw<3>(k, q, n_beams, lognw, elem_mode, st);
+        case 4: return rk45_by_nw<4>(k, q, n_beams, lognw, elem_mode, st);
+        case 5: return rk45_by_nw<5>(k, q, n_beams, lognw, elem_mode, st);
+        case 6: return rk45_by_nw<6>(k, q, n_beams, lognw, elem_mode, st);
+        default: return hipErrorInvalidValue;
+    }
+#endif
+}
 
 hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st) {
 #ifdef CRB_FAST_BUILD  // kernel-tuning build (make fast): only the config-3 instance

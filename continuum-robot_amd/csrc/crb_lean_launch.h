@@ -14,4 +14,8 @@ hipError_t launch_lean(const KParams<float>& k, int n_beams, int levels, int log
 // over beams blockIdx.x, blockIdx.x + n_groups, ...)
 hipError_t launch_stage_lean(const KParams<double>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
 hipError_t launch_stage_lean(const KParams<float>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
+// launches crb_rk45_kernel with the lean RHS (plans without gravity, one beam per workgroup of 2^lognw <= 4
+// waves, levels 3..6); hipErrorInvalidValue otherwise
+hipError_t launch_rk45_lean(const KParams<double>& k, const Rk45Params& q, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st);
+hipError_t launch_rk45_lean(const KParams<float>& k, const Rk45Params& q, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st);
 }  // namespace crb

@@ -917,6 +917,12 @@ int launch_rk45(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hip
 #ifdef CRB_FAST_BUILD
     return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: rk45 not built");
 #else
+    // plans without gravity, one beam per workgroup of <= 4 waves: the lean RHS (crb_lean.hip)
+    if (!(p->flags & CRB_FORCE_GRAVITY) && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 2 && p->levels >= 3 &&
+        p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr) {
+        HIP_TRY(crb::launch_rk45_lean(k, q, p->B, p->levels, p->lognw, p->elem_mode, st));
+        return CRB_OK;
+    }
     switch (p->levels) {
         case 0: return launch_rk45_lv<T, 0>(p, k, q, st);
         case 1: return launch_rk45_lv<T, 1>(p, k, q, st);

@@ -646,3 +646,29 @@ def test_native_feedback_rollout_entry_point_contract():
         t = t + dt
     torch.cuda.synchronize()
     assert torch.equal(ens.state, ref.state)
+
+
+@pytest.mark.parametrize("n_e,kind", [(64, "linear"), (100, "mixed"), (200, "nonlinear")])
+def test_adaptive_rk45_lean_rhs_equals_general_rhs(n_e, kind, monkeypatch):
+    """crb_solve_rk45 evaluates the RHS through the lean exchange structure for plans without gravity (1, 2
+    and 4 waves per beam here); the general RHS (CRB_DISABLE_LEAN) must take the same steps and land on
+    the same state up to rounding, in fp64 and in fp32."""
+    kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)] if kind == "mixed" else kind
+    cols = nitinol_columns(n_e, kinds)
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    B = 3
+    amps = 0.05 * (1.0 + np.arange(B))
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 2e-3)):
+        out = []
+        for disable in (False, True):
+            if disable:
+                monkeypatch.setenv("CRB_DISABLE_LEAN", "1")
+            else:
+                monkeypatch.delenv("CRB_DISABLE_LEAN", raising=False)
+            ens = ensemble(cols, B, kw, dtype=dtype)
+            st = ens.solve_rk45(4e-4, rtol=1e-6, atol=1e-9, impulse_amp=amps, t0=0.0)
+            assert (np.asarray(st["status"]) == 0).all()
+            out.append((np.asarray(st["accepted"]), np.asarray(st["nfev"]), ens.unpack_state().double().cpu().numpy()))
+        if dtype == torch.float64:
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        assert rel_err(out[0][2], out[1][2]) < tol
