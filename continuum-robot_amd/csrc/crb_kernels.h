@@ -58,6 +58,8 @@ struct KParams {
     const T* xs;               // MODE_STAGE: this stage's state (== x at stage 0)
     T* acc;                    // MODE_STAGE: RK4 accumulator [B][2][n_node][4]
     int stage;                 // MODE_STAGE: 0..3
+    const double* t_dev;       // MODE_STAGE: device clock of the step being taken (hipGraph replay: the launch
+                               // arguments must not change from step to step); nullptr = t0 holds the stage time
     T* rec_out;                // MODE_STEP: [B][n_rec] strided record of one DOF, or nullptr
     int rec_slot, rec_comp;    // recording thread (slot) and component 0..5 of {q, v}
     int rec_every, rec_n;
@@ -73,6 +75,19 @@ struct KParams {
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
+// stage time of the stage-split stepper: passed by value, or derived from the device clock with the host
+// loop's own operations (t, t + dt/2, t + dt/2, t + dt, each a single IEEE addition)
+template <typename T>
+__device__ __forceinline__ double stage_time(const KParams<T>& p) {
+    if (!p.t_dev) return p.t0;
+    const double t = *p.t_dev;
+    return p.stage == 0 ? t : (p.stage == 3 ? __dadd_rn(t, p.dt) : __dadd_rn(t, 0.5 * p.dt));
+}
+// (one thread) sets the device clock, or advances it by one step: t <- t + dt
+template <int UNUSED>
+__global__ void crb_clock_kernel(double* t, double dt, double set_to, int set) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *t = set ? set_to : __dadd_rn(*t, dt);
+}
 // element kinds over the whole topology: mixed (per-lane branch), all linear, all nonlinear as shipped
 // (CRB_CORRECTED_AXIAL plans take the mixed path).  Threads without an element carry zero coefficients,
 // for which every formula returns zero forces.
@@ -321,7 +336,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
                 if (p.stage > 0) { acc[c] = p.acc[xoff + c]; acc[3 + c] = p.acc[xoff + plane + c]; }
             }
         }
-        const T av = (p.t0 < p.duration) ? amp : T(0);
+        const T av = (stage_time(p) < p.duration) ? amp : T(0);
         T uadd[3], a[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) uadd[c] = uh[c] + ((c == p.imp_dof) ? av : T(0));
@@ -1219,7 +1234,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     const T w = (p.stage == 0 || p.stage == 3) ? T(1) : T(2);
     const T cs = (p.stage == 2) ? T(p.dt) : T(0.5 * p.dt);
     const T dt6 = T(p.dt / 6.0);
-    const bool imp_on = p.t0 < p.duration;
+    const bool imp_on = stage_time(p) < p.duration;
 
     ElemCoef<T> ec;
     T dragc = T(0), hm_own = T(0), hm_left = T(0);

@@ -209,7 +209,9 @@ int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void
 /* The closed loop of examples/lqr_control.py:95-125 as ONE call: n_steps RK4 steps with u = K (r - x)
  * re-evaluated at every stage (crb_feedback_force, then crb_rk4_stage), all launches issued from here
  * (fp64 plans).  work: device scratch of crb_feedback_work_bytes(plan) bytes (three state-sized buffers and
- * one force-sized buffer; contents need not be initialised).  Returns the accumulated clock in *t_end. */
+ * one force-sized buffer and the device clock; contents need not be initialised).  Returns the accumulated clock
+ * in *t_end.  CRB_USE_GRAPH=1 in the environment replays one captured step as a hipGraph on a stream of the
+ * plan's own (ordered after / before the caller's stream by events). */
 size_t crb_feedback_work_bytes(const crb_plan* plan);
 int crb_step_rk4_feedback(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const void* gain,
                           const void* ref, const crb_input_desc* input, void* work, double* t_end, void* stream);

@@ -7,6 +7,8 @@ Tolerances: north_star asks 1e-6 relative fp64; the HIP path and the reference d
 by rounding (cyclic-reduction solve vs explicit inverse, regrouped polynomial, FMA contraction), so
 the fp64 assertions are far tighter and written next to each check.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -607,7 +609,7 @@ def test_native_feedback_rollout_entry_point_contract():
 
     lib = nat.load()
     cols = nitinol_columns(70, "linear")
-    B, dt, steps = 3, 2e-5, 7
+    B, dt, steps = 3, 2e-5, 12
     rng = np.random.default_rng(3)
     ens = ensemble(cols, B, dict(enable_gravity=True))
     n = ens.n
@@ -615,7 +617,7 @@ def test_native_feedback_rollout_entry_point_contract():
     x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
     ens.set_state(x0)
     work = torch.empty((int(lib.crb_feedback_work_bytes(ens.plan.h)),), dtype=torch.uint8, device=ens.device)
-    assert work.numel() == 3 * ens.state.numel() * 8 + ens.state.numel() * 4
+    assert work.numel() == 3 * ens.state.numel() * 8 + ens.state.numel() * 4 + 256
     t_end = C.c_double(-1.0)
     vp = lambda t: C.c_void_p(t.data_ptr())
     # bad arguments
@@ -646,6 +648,23 @@ def test_native_feedback_rollout_entry_point_contract():
         t = t + dt
     torch.cuda.synchronize()
     assert torch.equal(ens.state, ref.state)
+    # opt-in hipGraph replay of one captured step (CRB_USE_GRAPH=1; a second rollout reuses the captured step):
+    # an impulse that switches off mid-run is timed by the device clock exactly as by the host loop
+    amps = torch.tensor([0.1, 0.2, 0.3], dtype=torch.float64, device=ens.device)
+    finals = []
+    for graph in (True, False):
+        e = ensemble(cols, B, dict(enable_gravity=True))
+        e.set_state(x0)
+        if graph:
+            os.environ["CRB_USE_GRAPH"] = "1"
+        try:
+            e.step_feedback(10, dt, gain, impulse_amp=amps, impulse_duration=5.5 * dt)
+            e.step_feedback(10, dt, gain, impulse_amp=amps, impulse_duration=5.5 * dt)
+        finally:
+            os.environ.pop("CRB_USE_GRAPH", None)
+        assert abs(e.time - 20 * dt) < 1e-15
+        finals.append(e.unpack_state())
+    assert torch.equal(finals[0], finals[1])
 
 
 @pytest.mark.parametrize("n_e,kind", [(64, "linear"), (100, "mixed"), (200, "nonlinear")])
