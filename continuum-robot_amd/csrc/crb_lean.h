@@ -1,0 +1,654 @@
+// crb_lean.h -- the lean kernels: fused multi-step RK4 stepper (the headline path), lean RHS, one-stage kernel
+// of the stage-split stepper.  Register-resident solve tables, merged exchange rounds, DPP lane shifts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "crb_generic.h"
+
+namespace crb {
+
+// ------------------------------------------------------------------ lean fused stepper
+// crb_step_lean_kernel: the stepper for plans without gravity and calls without a held input
+// (BASELINE configs 3/4), one beam per workgroup of NW = 2^LOGNW waves, everything compile-time:
+//   * exchange rounds merged.  Positions of the NEXT stage are known when a stage starts
+//     (q_next = x_q + c*v_stage), so they ride on this stage's force exchange instead of costing a
+//     round of their own; the force exchange itself is merged with cyclic-reduction level 0: a
+//     thread publishes {q_next, p = u - f_right + drag, f_left} once and rebuilds r of both
+//     neighbours from what it reads (r_{i-1} = p_{i-1} - f_left_i, r_{i+1} = p_{i+1} - f_left_{i+2}).
+//     Rounds per RHS: 1 + (LV-1) instead of 2 + LV; barriers: max(LOGNW,1) [0 for one wave].
+//   * round A moves 16-byte LDS words (record = 10 fp64 / 12 fp32 values per thread, padded so
+//     that ds_read/write_b128 are bank-conflict free); lane +-1 shifts use DPP wave_shr/wave_shl
+//     (no LDS round trip), larger lane shifts ds_bpermute.
+template <typename T>
+struct LeanRec {                    // [qn0 qn1 qn2 - | p0 p1 p2 fl0 | fl1 fl2 (- -)]
+    static constexpr int N = sizeof(T) == 8 ? 10 : 12;   // 80 B / 48 B: conflict-free 16-byte accesses
+    static constexpr int V = 16 / sizeof(T);              // values per 16-byte LDS word
+};
+template <typename T>
+__host__ __device__ constexpr size_t lean_lds_bytes(int NT, int lognw) {
+    // round A records (+1 all-zero "no neighbour" record; double-buffered when round A is the only
+    // barrier round) + SoA buffers (+1 zero column) of the cross-wave levels 1..lognw-1
+    return sizeof(T) * (size_t(NT + 1) * LeanRec<T>::N * (lognw == 1 ? 2 : 1) +
+                        3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
+}
+
+// wave_shr:1 / wave_shl:1 with bound_ctrl: a lane without a source lane reads 0 and no "old" value has
+// to be materialised first (update_dpp(0, ..) costs one extra v_mov per DPP).
+__device__ __forceinline__ double dpp_from_lower(double x) {  // value held by lane-1 (0 into lane 0)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_higher(double x) {  // value held by lane+1 (0 into lane 63)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float dpp_from_lower(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_higher(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x130, 0xf, 0xf, true));
+}
+// Value of lane-D / lane+D of the same wave.  D <= DPP_MAX: chained DPP wave shifts (VALU, no
+// LDS round trip; lanes shifted in from outside the wave read 0).  Larger D: ds_bpermute; a lane
+// index outside the wave wraps to some lane of the SAME beam -- callers only ever multiply such
+// a value by a multiplier that is exactly 0 (no neighbour at that stride).
+#ifndef CRB_DPP_MAX
+#define CRB_DPP_MAX 4
+#endif
+// wave priorities per phase of a stage (s_setprio; -1 = leave unchanged)
+#ifndef CRB_P_FORCE
+#define CRB_P_FORCE 0
+#endif
+#ifndef CRB_P_XCHG
+#define CRB_P_XCHG 2
+#endif
+#ifndef CRB_P_L1
+#define CRB_P_L1 -1
+#endif
+#ifndef CRB_P_TAIL
+#define CRB_P_TAIL 1
+#endif
+#ifndef CRB_P_FIN
+#define CRB_P_FIN -1
+#endif
+#ifndef CRB_SOA
+#define CRB_SOA 1
+#endif
+#define CRB_SETPRIO(v) do { if ((v) >= 0) __builtin_amdgcn_s_setprio((v) < 0 ? 0 : (v)); } while (0)
+template <typename T, int D>
+__device__ __forceinline__ T lane_lower(T x, int lane) {
+    if (D <= CRB_DPP_MAX) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) x = dpp_from_lower(x);
+        return x;
+    }
+    return __shfl(x, lane - D, 64);
+}
+template <typename T, int D>
+__device__ __forceinline__ T lane_higher(T x, int lane) {
+    if (D <= CRB_DPP_MAX) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) x = dpp_from_higher(x);
+        return x;
+    }
+    return __shfl(x, lane + D, 64);
+}
+
+// 16-byte LDS access of the V values starting at element index I (I % V == 0) of a record
+template <typename T>
+struct Vec16 {
+    typedef T type __attribute__((ext_vector_type(16 / sizeof(T))));
+};
+template <typename T, int FIRST, int LAST>
+__device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
+    constexpr int V = LeanRec<T>::V;
+    typedef typename Vec16<T>::type vec;
+#pragma unroll
+    for (int w = FIRST / V; w <= LAST / V; ++w) {
+        const vec v = *reinterpret_cast<const vec*>(rec + w * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) out[w * V + k] = v[k];
+    }
+}
+
+// Reduction levels 1..LV-1 and the final block inverse of the lean kernels, given r after level 0.
+// Levels whose stride stays inside the workgroup's waves-per-beam interleave (l < LOGNW) go through LDS
+// columns + a barrier, the others are in-wave lane shifts.  A missing neighbour contributes through a
+// multiplier that is exactly 0, so whatever finite value the shift returns there is harmless.
+template <typename T, int LV, int LOGNW>
+__device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* ldsB, int t, int lane, int j, int S,
+                                                 bool valid, T r[3], T a[3]) {
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    T rlo[3], rhi[3];
+#pragma unroll
+    for (int l = 1; l < LV; ++l) {
+        if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
+            if (l == 1) CRB_SETPRIO(CRB_P_L1);
+            const int st = 1 << l;
+            T* buf = ldsB + size_t(l - 1) * 3 * (NT + 1);
+            buf[t] = r[0]; buf[(NT + 1) + t] = r[1]; buf[2 * (NT + 1) + t] = r[2];
+            __syncthreads();
+            const int tl = (valid && j - st >= 0) ? thread_of(j - st) : NULLT;
+            const int th = (valid && j + st < S) ? thread_of(j + st) : NULLT;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
+        } else {
+            if (l == LOGNW) CRB_SETPRIO(CRB_P_TAIL);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                switch (l - LOGNW) {
+                    case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
+                    case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
+                    case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
+                    case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
+                    case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
+                    default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
+                }
+            }
+        }
+        pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
+    }
+    CRB_SETPRIO(CRB_P_FIN);
+    pcr_apply_final<T>(cf.fin, r, a);
+}
+
+template <typename T, int LV, int LOGNW, int EM>
+__device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool corrected, const SolveCoef<T, LV>& cf, T* lds3, int t,
+                                         int lane, int j, int S, bool valid, const T sq[3], const T sv[3], const T uadd[3], T a[3]) {
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    T* const ldsQ = lds3;                           // [3][NT+1]  stage positions
+    T* const ldsA = lds3 + 3 * size_t(NT + 1);      // [6][NT+1]  p0..2, fl0..2
+    T* const ldsB = lds3 + 9 * size_t(NT + 1);      // [LOGNW-1][3][NT+1]
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+    // -- the left neighbour's position (its own exchange: stage states are arbitrary combinations here)
+    T qL[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(sq[c], lane);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ldsQ[size_t(c) * (NT + 1) + t] = sq[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = ldsQ[size_t(c) * (NT + 1) + t_l1];
+    }
+    T fl[3], fr[3];
+    if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
+    else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
+    else elem_force<T>(ec, qL, sq, corrected, fl, fr);
+    T pp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pp[c] = uadd[c] - fr[c];
+    pp[1] += drag_force<T>(dragc, sv[1]);
+    // -- merged exchange round {p, fl} + level 0.  The barrier of the q exchange above orders the previous
+    //    call's reads of these columns before this call's writes (and vice versa for the q columns).
+    T r[3], rlo[3], rhi[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+            r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+            rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+        }
+    } else {
+        auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { col(c, t) = pp[c]; col(3 + c, t) = fl[c]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rlo[c] = col(c, t_l1) - fl[c];
+            r[c] = pp[c] - col(3 + c, t_r1);
+            rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+        }
+    }
+    pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+    lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
+}
+
+// EM (EM_*): the element kind when the whole topology has one; the force evaluation is then straight-line
+// code that the scheduler interleaves with the tail of the previous stage's reduction (measured +8 %
+// over the per-lane branch of EM_MIXED; a wave-uniform run-time branch does not get it).
+template <typename T, int LV, int LOGNW, bool GRAV, int EM>
+// fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: 3 waves/SIMD (168 VGPRs; 4 waves/SIMD spills)
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_step_lean_kernel(const KParams<T> p) {
+    static_assert(LV >= 1, "lean stepper needs at least one reduction level");
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N, RV = LeanRec<T>::V;
+    constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
+    // fp64 round A is laid out as 9 columns [qn0..2 p0..2 fl0..2][NT+1] moved by 8-byte accesses (a 16-byte LDS
+    // store costs 13 cycles of the store path against 2 x 6 for two 8-byte ones); fp32 keeps 16-byte records
+    constexpr bool SOA = CRB_SOA && sizeof(T) == 8;
+    auto recA = [](T* base, int th, int k) -> T& { return SOA ? base[size_t(k) * (NT + 1) + th] : base[size_t(th) * RN + k]; };
+    extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
+    T* const ldsA = reinterpret_cast<T*>(crb_smem);
+    T* const ldsB = ldsA + size_t(NT + 1) * RN * (LOGNW == 1 ? 2 : 1);  // [level-1][3][NT+1]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int S = p.S;
+    const int j = (lane << LOGNW) | wave;
+    const int beam = blockIdx.x;
+    const bool valid = j < S;
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    // LDS positions of the stride-1 / stride-2 neighbours (NULLT outside the beam)
+    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+
+    if (LOGNW > 0 && t == 0) {  // zero the "no neighbour" slots once
+#pragma unroll
+        for (int k = 0; k < RN; ++k) {
+            recA(ldsA, NULLT, k) = T(0);
+            if (LOGNW == 1) recA(ldsA + size_t(NT + 1) * RN, NULLT, k) = T(0);
+        }
+#pragma unroll
+        for (int l = 1; l < LOGNW; ++l)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ldsB[(size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
+    }
+
+    // ---- per-thread constants
+    ElemCoef<T> ec;
+    T dragc = T(0);
+    SolveCoef<T, LV> cf;
+    if (valid) {
+        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];
+        ec = sc.elem;
+        dragc = (p.flags & 1u) ? sc.drag : T(0);
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+            const T* src = p.pcr_levels + size_t(beam) * p.lv_stride + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+#pragma unroll
+            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(beam) * p.fin_stride + size_t(j) * PCR_FINAL_VALS + k];
+    } else {
+        ec.kind = KIND_NONE;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ec.c[k] = T(0);
+#pragma unroll
+        for (int l = 0; l < LV; ++l)
+#pragma unroll
+            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
+    }
+    const bool corrected = (p.flags & 4u) != 0;
+    // GRAV: gravity on the canonical cantilever (only node 0 constrained), where the reference's reduced-index
+    // addressing (gravity_forces.py:104-146) is nearest-neighbour: segment j averages the rotations of slots j
+    // and j+1 (slot j alone at the tip) and loads slots j and j+1.  A thread evaluates segment j AND segment
+    // j-1 itself (it knows phi of slots j-1, j, j+1), so gravity needs no exchange of its own.
+    T hm_own = T(0), hm_left = T(0), phiR = T(0);
+    const bool has_right = valid && j + 1 < S;
+    if (GRAV && valid) {
+        hm_own = p.slot[size_t(beam) * p.slot_stride + j].half_mass;
+        if (j >= 1) hm_left = p.slot[size_t(beam) * p.slot_stride + j - 1].half_mass;
+    }
+
+    // ---- state
+    const size_t node = size_t(valid ? j + p.off : 0);
+    const size_t plane = size_t(p.n_node) * 4;
+    const size_t xoff = size_t(beam) * 2 * plane + node * 4;
+    T xq[3] = {T(0), T(0), T(0)}, xv[3] = {T(0), T(0), T(0)};
+    T amp = T(0);
+    if (valid) {
+        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xq[c] = p.x[xoff + c] * sc.mask[c];
+            xv[c] = p.x[xoff + plane + c] * sc.mask[c];
+        }
+        if (p.amp && j == p.imp_slot) amp = p.amp[beam];
+    }
+
+    // ---- left neighbour's q for the very first stage
+    T qL[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(xq[c], lane);  // lane 0 reads 0 = clamped / absent root
+        if (GRAV) phiR = lane_higher<T, 1>(xq[2], lane);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) recA(ldsA, t, c) = xq[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = recA(ldsA, t_l1, c);
+        if (GRAV) phiR = recA(ldsA, t_r1, 2);
+        __syncthreads();
+    }
+
+    const T dt = T(p.dt), hdt = T(0.5 * p.dt), dt6 = T(p.dt / 6.0);
+    double tc = p.t0;
+    T accq[3], accv[3], sq[3], sv[3];  // RK4 accumulators and stage state
+    for (int step = 0; step < p.n_steps; ++step) {
+        const double t_half = __dadd_rn(tc, 0.5 * p.dt), t_full = __dadd_rn(tc, p.dt);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { accq[c] = T(0); accv[c] = T(0); sq[c] = xq[c]; sv[c] = xv[c]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double ts = (s == 0) ? tc : ((s == 3) ? t_full : t_half);
+            const bool imp_on = ts < p.duration;  // wave-uniform: the impulse selector stays on the scalar unit
+            const T w = (s == 0 || s == 3) ? T(1) : T(2);
+            const T cs = (s == 2) ? dt : hdt;
+
+            // -- positions of the next stage (or of the next step after stage 3)
+            T qn[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                accq[c] += w * sv[c];
+                qn[c] = (s == 3) ? (xq[c] + dt6 * accq[c]) : (xq[c] + cs * sv[c]);
+            }
+            // -- element force of the element left of this node
+            T fl[3], fr[3];
+            CRB_SETPRIO(CRB_P_FORCE);
+            if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
+            else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
+            else elem_force<T>(ec, qL, sq, corrected, fl, fr);
+            CRB_SETPRIO(CRB_P_XCHG);
+            T pp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pp[c] = ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];
+            pp[1] += drag_force<T>(dragc, sv[1]);
+            if (GRAV) {
+                T g_own[2], g_left[2];
+                gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
+                if (LOGNW == 0) {  // segment j-1 IS the left lane's own segment: take its result (bit-identical), one sincos less
+                    g_left[0] = lane_lower<T, 1>(g_own[0], lane);
+                    g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+                } else {
+                    gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+                }
+                pp[0] += g_own[0] + g_left[0];
+                pp[1] += g_own[1] + g_left[1];
+            }
+
+            // -- round A: publish {qn, p, fl}; rebuild r of this node and of both stride-1 neighbours.
+            // Outside the beam a neighbour reads as zeros (DPP edge / all-zero LDS record).
+            T r[3], rlo[3], rhi[3];
+            if (LOGNW == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    // (shuffles stay outside any condition: every lane must take part.  Lanes past
+                    //  the last slot are padding threads whose p and fl are 0, wave edges shift in 0.)
+                    if (GRAV && c == 2) phiR = lane_higher<T, 1>(qn[2], lane);
+                    qL[c] = lane_lower<T, 1>(qn[c], lane);
+                    rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+                    r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+                    rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+                }
+            } else {
+                T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT + 1) * RN : 0);
+                if (SOA) {
+                    recA(bufA, t, 0) = qn[0]; recA(bufA, t, 1) = qn[1]; recA(bufA, t, 2) = qn[2];
+                    recA(bufA, t, 3) = pp[0]; recA(bufA, t, 4) = pp[1]; recA(bufA, t, 5) = pp[2];
+                    recA(bufA, t, 6) = fl[0]; recA(bufA, t, 7) = fl[1]; recA(bufA, t, 8) = fl[2];
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {   // what level 0 needs first, the next stage's qL last
+                        rlo[c] = recA(bufA, t_l1, 3 + c) - fl[c];
+                        r[c] = pp[c] - recA(bufA, t_r1, 6 + c);
+                        rhi[c] = recA(bufA, t_r1, 3 + c) - recA(bufA, t_r2, 6 + c);
+                    }
+                    if (GRAV) phiR = recA(bufA, t_r1, 2);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) qL[c] = recA(bufA, t_l1, c);
+                } else {
+                typedef typename Vec16<T>::type vec;
+                T out[RN];
+                out[0] = qn[0]; out[1] = qn[1]; out[2] = qn[2]; out[3] = T(0);
+                out[4] = pp[0]; out[5] = pp[1]; out[6] = pp[2];
+                out[7] = fl[0]; out[8] = fl[1]; out[9] = fl[2];
+#pragma unroll
+                for (int k = 10; k < RN; ++k) out[k] = T(0);
+                vec* rec = reinterpret_cast<vec*>(bufA + size_t(t) * RN);
+#pragma unroll
+                for (int wv = 0; wv < RN / RV; ++wv) {
+                    vec v;
+#pragma unroll
+                    for (int k = 0; k < RV; ++k) v[k] = out[wv * RV + k];
+                    rec[wv] = v;
+                }
+                __syncthreads();
+                T L[RN], R1[RN], R2[RN];
+                rec_load<T, 0, 6>(bufA + size_t(t_l1) * RN, L);
+                rec_load<T, GRAV ? 2 : 4, 9>(bufA + size_t(t_r1) * RN, R1);
+                rec_load<T, 7, 9>(bufA + size_t(t_r2) * RN, R2);
+                if (GRAV) phiR = R1[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    qL[c] = L[c];
+                    rlo[c] = L[4 + c] - fl[c];
+                    r[c] = pp[c] - R1[7 + c];
+                    rhi[c] = R1[4 + c] - R2[7 + c];
+                }
+                }
+            }
+            pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+
+            // -- remaining reduction levels and the final block inverse
+            T a[3];
+            lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
+
+            // -- RK4 bookkeeping
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                accv[c] += w * a[c];
+                sq[c] = qn[c];
+                sv[c] = (s == 3) ? (xv[c] + dt6 * accv[c]) : (xv[c] + cs * a[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { xq[c] = sq[c]; xv[c] = sv[c]; }
+        tc = t_full;
+        if (p.rec_out && valid && j == p.rec_slot && (step + 1) % p.rec_every == 0) {
+            T val = xq[0];
+#pragma unroll
+            for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? (c < 3 ? xq[c] : xv[c - 3]) : val;
+            p.rec_out[size_t(beam) * p.rec_n + (step + 1) / p.rec_every - 1] = val;
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            p.x[xoff + c] = xq[c];
+            p.x[xoff + plane + c] = xv[c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ lean stage kernel
+// crb_stage_lean_kernel: ONE RK4 stage of the stage-split stepper (crb_rk4_stage: the input force changes per
+// stage, e.g. LQR feedback u = K(r - x) evaluated by crb_feedback_force) with the lean stepper's machinery:
+// register-resident multipliers, one merged exchange round {p, f_left} + level 0, in-wave levels by DPP.
+// A launch is one RHS per beam, so what the generic stage kernel pays most for is re-reading the solve
+// tables (440 B per node) for every beam: here a workgroup keeps them in registers and walks over several
+// beams (shared-table plans; per-beam tables reload).  The left neighbour's q (and the right neighbour's
+// rotation for gravity) are plain global loads of the stage state: no exchange round for them.
+//   k = f(t_stage, xs, u_stage + impulse);  acc = (stage ? acc : 0) + w k;
+//   stage < 3: out = x + c k;   stage 3: x += dt/6 acc           (same contract as MODE_STAGE)
+template <typename T>
+__host__ __device__ constexpr size_t stage_lean_lds_bytes(int NT, int lognw) {
+    return sizeof(T) * (size_t(NT + 1) * 6 * (lognw == 1 ? 2 : 1) + 3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
+}
+template <typename T, int LV, int LOGNW, bool GRAV, int EM>
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_stage_lean_kernel(const KParams<T> p) {
+    static_assert(LV >= 1, "lean stage kernel needs at least one reduction level");
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
+    T* const ldsA = reinterpret_cast<T*>(crb_smem);                         // [1 or 2][6][NT+1]: p0..2, fl0..2
+    T* const ldsB = ldsA + size_t(NT + 1) * 6 * (LOGNW == 1 ? 2 : 1);       // [level-1][3][NT+1]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int S = p.S;
+    const int j = (lane << LOGNW) | wave;
+    const bool valid = j < S;
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+    if (LOGNW > 0 && t == 0) {
+#pragma unroll
+        for (int k = 0; k < 6 * (LOGNW == 1 ? 2 : 1); ++k) ldsA[size_t(k) * (NT + 1) + NULLT] = T(0);
+#pragma unroll
+        for (int l = 1; l < LOGNW; ++l)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ldsB[(size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
+    }
+    const bool shared_tables = p.slot_stride == 0 && p.lv_stride == 0 && p.fin_stride == 0;
+    const bool corrected = (p.flags & 4u) != 0;
+    const bool has_right = valid && j + 1 < S, has_left = valid && j >= 1;
+    const size_t node = size_t(valid ? j + p.off : 0);
+    const size_t plane = size_t(p.n_node) * 4;
+    const T w = (p.stage == 0 || p.stage == 3) ? T(1) : T(2);
+    const T cs = (p.stage == 2) ? T(p.dt) : T(0.5 * p.dt);
+    const T dt6 = T(p.dt / 6.0);
+    const bool imp_on = stage_time(p) < p.duration;
+
+    ElemCoef<T> ec;
+    T dragc = T(0), hm_own = T(0), hm_left = T(0);
+    T mask[3] = {T(0), T(0), T(0)}, maskL[3] = {T(0), T(0), T(0)};
+    SolveCoef<T, LV> cf;
+    auto load_tables = [&](int beam) {
+        if (valid) {
+            const SlotConst<T>* st = p.slot + size_t(beam) * p.slot_stride;
+            const SlotConst<T>& sc = st[j];
+            ec = sc.elem;
+            dragc = (p.flags & 1u) ? sc.drag : T(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { mask[c] = sc.mask[c]; maskL[c] = has_left ? st[j - 1].mask[c] : T(0); }
+            if (GRAV) { hm_own = sc.half_mass; hm_left = has_left ? st[j - 1].half_mass : T(0); }
+#pragma unroll
+            for (int l = 0; l < LV; ++l) {
+                const T* src = p.pcr_levels + size_t(beam) * p.lv_stride + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(beam) * p.fin_stride + size_t(j) * PCR_FINAL_VALS + k];
+        } else {
+            ec.kind = KIND_NONE;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ec.c[k] = T(0);
+#pragma unroll
+            for (int l = 0; l < LV; ++l)
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
+        }
+    };
+    if (shared_tables) load_tables(0);
+
+    int it = 0;
+    for (int beam = blockIdx.x; beam < p.B; beam += gridDim.x, ++it) {
+        if (!shared_tables) load_tables(beam);
+        // ---- this stage's state, the neighbours' pieces of it, the input force
+        const size_t xoff = size_t(beam) * 2 * plane + node * 4;
+        T sq[3] = {T(0), T(0), T(0)}, sv[3] = {T(0), T(0), T(0)}, qL[3] = {T(0), T(0), T(0)}, uin[3] = {T(0), T(0), T(0)};
+        T x0q[3] = {T(0), T(0), T(0)}, x0v[3] = {T(0), T(0), T(0)}, aq[3] = {T(0), T(0), T(0)}, av[3] = {T(0), T(0), T(0)};
+        T phiR = T(0), amp = T(0);
+        typedef T rec4 __attribute__((ext_vector_type(4)));
+        if (valid) {
+            // a node record is 4 values = one aligned 32-byte (fp64) / 16-byte (fp32) vector: whole-record
+            // loads instead of three scalar ones (the slots of a wave are every NW-th node, so scalar loads
+            // would pull each 128-byte line through L1 once per component: measured 31.7 -> 24 us)
+            auto ldrec = [](const T* ptr) { return *reinterpret_cast<const rec4*>(ptr); };
+            const rec4 rq = ldrec(p.xs + xoff), rv = ldrec(p.xs + xoff + plane);
+            const rec4 bq = ldrec(p.x + xoff), bv = ldrec(p.x + xoff + plane);
+            rec4 rl = rec4{T(0), T(0), T(0), T(0)}, cq = rl, cv = rl, ru = rl;
+            if (has_left) rl = ldrec(p.xs + xoff - 4);
+            if (p.stage > 0) { cq = ldrec(p.acc + xoff); cv = ldrec(p.acc + xoff + plane); }
+            if (p.u_held) ru = ldrec(p.u_held + size_t(beam) * plane + node * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sq[c] = rq[c] * mask[c];
+                sv[c] = rv[c] * mask[c];
+                qL[c] = rl[c] * maskL[c];
+                x0q[c] = bq[c] * mask[c];
+                x0v[c] = bv[c] * mask[c];
+                aq[c] = cq[c];
+                av[c] = cv[c];
+                uin[c] = ru[c];
+            }
+            if (GRAV && has_right) phiR = p.xs[xoff + 4 + 2];
+            if (p.amp && j == p.imp_slot) amp = p.amp[beam];
+        }
+        // ---- forces on this node from its own element, drag, gravity, inputs
+        T fl[3], fr[3];
+        CRB_SETPRIO(CRB_P_FORCE);
+        if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
+        else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
+        else elem_force<T>(ec, qL, sq, corrected, fl, fr);
+        CRB_SETPRIO(CRB_P_XCHG);
+        T pp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pp[c] = uin[c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];
+        pp[1] += drag_force<T>(dragc, sv[1]);
+        if (GRAV) {
+            T g_own[2], g_left[2];
+            gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
+            if (LOGNW == 0) {  // (as in the stepper: the left lane's own segment)
+                g_left[0] = lane_lower<T, 1>(g_own[0], lane);
+                g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+            } else {
+                gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+            }
+            pp[0] += g_own[0] + g_left[0];
+            pp[1] += g_own[1] + g_left[1];
+        }
+        // ---- round A: publish {p, fl}, rebuild r of this node and of both stride-1 neighbours, level 0
+        T r[3], rlo[3], rhi[3];
+        if (LOGNW == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+                r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+                rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+            }
+        } else {
+            T* bufA = ldsA + ((LOGNW == 1 && (it & 1)) ? size_t(NT + 1) * 6 : 0);
+            auto col = [&](int k, int th) -> T& { return bufA[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { col(c, t) = pp[c]; col(3 + c, t) = fl[c]; }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rlo[c] = col(c, t_l1) - fl[c];
+                r[c] = pp[c] - col(3 + c, t_r1);
+                rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+            }
+        }
+        pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+        T a[3];
+        lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
+        // ---- RK4 bookkeeping of this stage
+        if (valid) {
+            auto strec = [](T* ptr, const T v[3]) { *reinterpret_cast<rec4*>(ptr) = rec4{v[0], v[1], v[2], T(0)}; };
+            T nq[3], nv[3], oq[3], ov[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                nq[c] = (p.stage ? aq[c] : T(0)) + w * sv[c];
+                nv[c] = (p.stage ? av[c] : T(0)) + w * a[c];
+                oq[c] = (p.stage < 3) ? x0q[c] + cs * sv[c] : x0q[c] + dt6 * nq[c];
+                ov[c] = (p.stage < 3) ? x0v[c] + cs * a[c] : x0v[c] + dt6 * nv[c];
+            }
+            if (p.stage < 3) {   // (whole records: the pad value is written as 0)
+                strec(p.out + xoff, oq); strec(p.out + xoff + plane, ov);
+                strec(p.acc + xoff, nq); strec(p.acc + xoff + plane, nv);
+            } else {
+                strec(p.x + xoff, oq); strec(p.x + xoff + plane, ov);
+            }
+        }
+        // LOGNW >= 2: the level-1 barrier above orders this beam's round-A reads before the next beam's
+        // round-A writes; LOGNW == 1 alternates two round-A buffers; LOGNW == 0 uses no LDS
+    }
+}
+
+}  // namespace crb

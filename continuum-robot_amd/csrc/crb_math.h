@@ -1,7 +1,7 @@
 // crb_math.h -- per-node / per-element arithmetic of the beam hot path.
 //
 // Everything here is a small inline function of VALUES (no memory, no thread ids), so the
-// same source is compiled into the gfx950 kernels (crb_kernels.hip) and, for CPU-only
+// same source is compiled into the gfx950 kernels (crb_kernels.h) and, for CPU-only
 // debugging of the kernel arithmetic, into tests/native/crb_emul.cpp (test harness; it is
 // not a product path).  Reference citations are file:line under
 // /root/reference/src/continuum_robot/models/.

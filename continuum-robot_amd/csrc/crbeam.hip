@@ -33,7 +33,7 @@ struct crb_plan {
     size_t slot_stride = 0, lv_stride = 0, fin_stride = 0;  // per-beam coefficient tables (0 = shared)
     bool canonical_gravity = false;  // gravity index table is the nearest-neighbour pattern of the plain cantilever
     uint32_t flags = 0;
-    int elem_mode = 0;           // EM_* (crb_kernels.h)
+    int elem_mode = 0;           // EM_* (crb_generic.h)
     double gx = 0, gy = 0;
     std::vector<int32_t> free_index;  // reduced -> full
     std::vector<int32_t> full2red;    // full -> reduced or -1

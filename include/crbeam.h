@@ -134,7 +134,7 @@ int crb_plan_get_free_index(const crb_plan* plan, int32_t* full_index);
 int crb_plan_get_pcr_tables(const crb_plan* plan, double* levels, double* final_, double* norms);
 /* Host copies of the per-slot constants the kernels keep in registers, for inspection/tests:
  *   drag [n_slots], half_mass [n_slots], mask [n_slots][3],
- *   grav [n_slots][12] = {phiA, phiB, segA[3], segB[3], comp[3], 0} (see crb_kernels.h GravTab),
+ *   grav [n_slots][12] = {phiA, phiB, segA[3], segB[3], comp[3], 0} (see crb_generic.h GravTab),
  *   elem_kind [n_slots] (0 none, 1 linear, 2 nonlinear; the element LEFT of the slot's node).
  * Any pointer may be NULL. */
 int crb_plan_get_slot_tables(const crb_plan* plan, double* drag, double* half_mass, double* mask, int16_t* grav,

@@ -199,7 +199,7 @@ def test_lean_stepper_sizes(n_e, B):
                                       (100, "PINNED"), (200, "NONE")])
 def test_lean_stepper_single_kind_topologies(kind, n_e, root):
     """Beams of ONE element kind take the lean stepper's straight-line force code (element mode
-    EM_LINEAR / EM_NONLINEAR, crb_kernels.h) for every waves-per-beam count.  With a root that keeps its
+    EM_LINEAR / EM_NONLINEAR, crb_lean.h) for every waves-per-beam count.  With a root that keeps its
     slot (PINNED or unconstrained) the first thread has no element to its left and runs the same formula
     on zero coefficients."""
     cols = nitinol_columns(n_e, kind, [root] + ["NONE"] * (n_e - 1))

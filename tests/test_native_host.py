@@ -1,7 +1,7 @@
 """CPU-side checks of the native library: it loads, exports the whole C ABI, and the tables a
 host-only plan (device = -1) builds reproduce the reference quantities.  No kernel is launched.
 
-The numpy "slot emulation" below applies the plan's tables exactly the way crb_kernels.h does
+The numpy "slot emulation" below applies the plan's tables exactly the way the kernels (crb_generic.h) do
 (one node per thread, neighbour exchange, index-table gravity, cyclic-reduction solve); it is a
 debugging model of the kernel's data flow, checked against the oracle and the golden vectors.
 """
