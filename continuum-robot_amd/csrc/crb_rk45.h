@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
             const double h = t_new - tc;
             h_abs = fabs(h);
             // stages 1..5
-#pragma unroll 1
+#pragma unroll
             for (int s = 1; s < 6; ++s) {
                 T ys[6], ks[6];
 #pragma unroll
