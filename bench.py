@@ -69,6 +69,8 @@ def parse():
                     help="RK4 steps fused per launch (0 = all of --steps); warmup uses launches of the same size, so "
                          "every stepper launch of a run is identical and rocprof's per-kernel average is the launch time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-all", action="store_true",
+                    help="after timing, compare EVERY beam of rank 0 with the oracle (open-loop configs; tens of CPU-seconds)")
     ap.add_argument("--hetero", action="store_true",
                     help="heterogeneous variant (SURVEY 8(d)): per-beam E, rho, r scaled by U(0.9, 1.1), seed 4321")
     return ap.parse_args()
@@ -262,6 +264,13 @@ def main():
             ref = ob.rk4_feedback(x0b, dt, args.steps, gain.cpu().numpy(), amp=float(amps[b].item()))
         check["rel_err_vs_oracle_last_beam"] = rel_err(state[b].double().cpu().numpy(), ref)
         check["tip_w_last_beam"] = float(state[b, ens.n - 2].item())
+        if args.verify_all and gain is None and not args.hetero:
+            X0 = np.zeros((B, 2 * ob.n)) if x0 is None else x0n
+            ref_all, _ = ob.rk4_impulse_batch(X0, dt, args.steps, amps.double().cpu().numpy())
+            got_all = state.double().cpu().numpy()
+            errs = np.linalg.norm(got_all - ref_all, axis=1) / np.maximum(np.linalg.norm(ref_all, axis=1), 1e-300)
+            check["rel_err_vs_oracle_all_beams_max"] = float(errs.max())
+            check["beams_compared"] = int(B)
 
     if rank == 0:
         value = B_total * ne * args.steps / wall
