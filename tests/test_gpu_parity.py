@@ -223,6 +223,22 @@ def test_corrected_axial_option_matches_oracle():
     assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
 
 
+def test_corrected_axial_option_on_a_lean_size_beam():
+    """CRB_CORRECTED_AXIAL on a beam long enough for the lean stepper (all-nonlinear topology: the corrected
+    force takes the per-lane element path, not the EM_NONLINEAR straight-line one)."""
+    cols = nitinol_columns(128, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    ob = oracle_beam(cols, corrected_axial=True, **kw)
+    ens = ensemble(cols, 2, kw, corrected_axial=True)
+    amps = np.array([0.1, 0.3])
+    ens.step(200, 2e-5, impulse_amp=amps)
+    ref, _ = ob.rk4_impulse_batch(np.zeros((2, 2 * ob.n)), 2e-5, 200, amps)
+    assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-9
+    plain = ensemble(cols, 2, kw)
+    plain.step(200, 2e-5, impulse_amp=amps)
+    assert rel_err(plain.unpack_state().cpu().numpy(), ref) > 1e-6   # the two element variants do differ
+
+
 def test_fp32_plan_tracks_fp64_within_measured_drift():
     """BASELINE config 4's dtype.  fp32 is NOT held to 1e-6: cond(M) ~ 1e4 costs ~4 digits
     (SURVEY §7); the tolerance here is the measured drift with margin, over the 200-step horizon."""
