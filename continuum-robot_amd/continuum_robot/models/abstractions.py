@@ -5,6 +5,8 @@ Mirrors the public surface of the reference's src/continuum_robot/models/abstrac
 same names, fields, defaults and error messages, so user code and tests written against the
 reference import and behave the same.
 """
+from __future__ import annotations
+
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
 from enum import Enum
@@ -24,6 +26,97 @@ class BoundaryConditionType(Enum):
     PINNED = "pinned"  # u and w constrained, phi free
 
 
+# ---------------------------------------------------------------- composition interfaces
+class AbstractForce(ABC):
+    """A force term f(x, t) -> ndarray over the position DOFs."""
+
+    @abstractmethod
+    def compute_forces(self, x: np.ndarray, t: float) -> np.ndarray:
+        ...
+
+    @abstractmethod
+    def is_enabled(self) -> bool:
+        ...
+
+
+class AbstractInputHandler(ABC):
+    """An additive modification of the input vector."""
+
+    @abstractmethod
+    def compute_input(self, x: np.ndarray, r: np.ndarray, t: float) -> np.ndarray:
+        ...
+
+    @abstractmethod
+    def is_enabled(self) -> bool:
+        ...
+
+
+# ---------------------------------------------------------------- structural interfaces
+class IBeam(ABC):
+    def __init__(self, segments: List[ISegment]):
+        self.segments = segments
+
+    @abstractmethod
+    def assemble_mass_matrix(self) -> np.ndarray:
+        ...
+
+    @abstractmethod
+    def create_stiffness_function(self) -> Callable:
+        ...
+
+    @abstractmethod
+    def apply_boundary_conditions(self, boundary_conditions: Dict) -> None:
+        ...
+
+    @abstractmethod
+    def get_constrained_dofs(self) -> List[int]:
+        ...
+
+
+class ISegmentFactory(ABC):
+    @abstractmethod
+    def create_segment(self, properties: Properties) -> ISegment:
+        ...
+
+    @abstractmethod
+    def detect_element_type(self, properties: Properties) -> ElementType:
+        ...
+
+
+class ISegment(ABC):
+    """A two-node element with DOFs [u1, w1, phi1, u2, w2, phi2]."""
+
+    def __init__(self, properties: Properties):
+        self.properties = properties
+        self.segment_id = properties.segment_id
+
+    @abstractmethod
+    def get_mass_matrix(self) -> np.ndarray:
+        ...
+
+    @abstractmethod
+    def get_stiffness_func(self) -> Union[np.ndarray, Callable[[np.ndarray], np.ndarray]]:
+        ...
+
+    @abstractmethod
+    def get_element_type(self) -> ElementType:
+        ...
+
+    def validate_properties(self) -> None:
+        return None  # Properties validates itself on construction
+
+    def get_properties(self) -> Properties:
+        return self.properties
+
+
+@dataclass
+class AssemblyContext:
+    global_dof_offset: int
+    node_start: int
+    node_end: int
+
+
+# ---------------------------------------------------------------- per-segment record
 _POSITIVE_FIELDS = (
     ("length", "Length"),
     ("elastic_modulus", "Elastic modulus"),
@@ -60,94 +153,6 @@ class Properties:
 
     def has_fluid_properties(self) -> bool:
         return self.wetted_area is not None and self.drag_coef is not None
-
-
-@dataclass
-class AssemblyContext:
-    global_dof_offset: int
-    node_start: int
-    node_end: int
-
-
-class ISegment(ABC):
-    """A two-node element with DOFs [u1, w1, phi1, u2, w2, phi2]."""
-
-    def __init__(self, properties: Properties):
-        self.properties = properties
-        self.segment_id = properties.segment_id
-
-    @abstractmethod
-    def get_mass_matrix(self) -> np.ndarray:
-        ...
-
-    @abstractmethod
-    def get_stiffness_func(self) -> Union[np.ndarray, Callable[[np.ndarray], np.ndarray]]:
-        ...
-
-    @abstractmethod
-    def get_element_type(self) -> ElementType:
-        ...
-
-    def validate_properties(self) -> None:
-        return None  # Properties validates itself on construction
-
-    def get_properties(self) -> Properties:
-        return self.properties
-
-
-class ISegmentFactory(ABC):
-    @abstractmethod
-    def create_segment(self, properties: Properties) -> ISegment:
-        ...
-
-    @abstractmethod
-    def detect_element_type(self, properties: Properties) -> ElementType:
-        ...
-
-
-class IBeam(ABC):
-    def __init__(self, segments: List[ISegment]):
-        self.segments = segments
-
-    @abstractmethod
-    def assemble_mass_matrix(self) -> np.ndarray:
-        ...
-
-    @abstractmethod
-    def create_stiffness_function(self) -> Callable:
-        ...
-
-    @abstractmethod
-    def apply_boundary_conditions(self, boundary_conditions: Dict) -> None:
-        ...
-
-    @abstractmethod
-    def get_constrained_dofs(self) -> List[int]:
-        ...
-
-
-class AbstractForce(ABC):
-    """A force term f(x, t) -> ndarray over the position DOFs."""
-
-    @abstractmethod
-    def compute_forces(self, x: np.ndarray, t: float) -> np.ndarray:
-        ...
-
-    @abstractmethod
-    def is_enabled(self) -> bool:
-        ...
-
-
-class AbstractInputHandler(ABC):
-    """An additive modification of the input vector."""
-
-    @abstractmethod
-    def compute_input(self, x: np.ndarray, r: np.ndarray, t: float) -> np.ndarray:
-        ...
-
-    @abstractmethod
-    def is_enabled(self) -> bool:
-        ...
 
 
 def create_properties_from_dataframe(df: pd.DataFrame, segment_id: int) -> Properties:
