@@ -217,7 +217,9 @@ __device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool co
 // EM (EM_*): the element kind when the whole topology has one; the force evaluation is then straight-line
 // code that the scheduler interleaves with the tail of the previous stage's reduction (measured +8 %
 // over the per-lane branch of EM_MIXED; a wave-uniform run-time branch does not get it).
-template <typename T, int LV, int LOGNW, bool GRAV, int EM>
+// HELD: a per-node input force held over the launch (zero-order-hold control, `u` of dynamic_system(t, x, u)
+// as an array): three more registers and three more additions per stage, so it is its own instantiation.
+template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false>
 // fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: 3 waves/SIMD (168 VGPRs; 4 waves/SIMD spills)
 __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_step_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
@@ -308,6 +310,11 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         }
         if (p.amp && j == p.imp_slot) amp = p.amp[beam];
     }
+    T uh[3] = {T(0), T(0), T(0)};
+    if (HELD && valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) uh[c] = p.u_held[size_t(beam) * plane + node * 4 + c];
+    }
 
     // ---- left neighbour's q for the very first stage
     T qL[3];
@@ -355,7 +362,10 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             CRB_SETPRIO(CRB_P_XCHG);
             T pp[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) pp[c] = ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];
+            for (int c = 0; c < 3; ++c) {
+                pp[c] = ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];
+                if (HELD) pp[c] += uh[c];
+            }
             pp[1] += drag_force<T>(dragc, sv[1]);
             if (GRAV) {
                 T g_own[2], g_left[2];

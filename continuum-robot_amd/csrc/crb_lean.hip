@@ -9,17 +9,25 @@ namespace crb {
 namespace {
 typedef CRB_LEAN_T T;
 
-template <int LV, int LOGNW, bool GRAV, int EM>
-hipError_t one(const KParams<T>& k, int n_beams, hipStream_t st) {
+template <int LV, int LOGNW, bool GRAV, int EM, bool HELD>
+hipError_t one_held(const KParams<T>& k, int n_beams, hipStream_t st) {
     const dim3 grid(n_beams), block(64 << LOGNW);
     const size_t smem = lean_lds_bytes<T>(64 << LOGNW, LOGNW);
     if (smem > 64 * 1024) {  // dynamic LDS above 64 KiB is opt-in per kernel (the CU has 160 KiB)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM>), grid, block, smem, st, k);
+    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD>), grid, block, smem, st, k);
     return hipGetLastError();
+}
+template <int LV, int LOGNW, bool GRAV, int EM>
+hipError_t one(const KParams<T>& k, int n_beams, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    return one_held<LV, LOGNW, GRAV, EM, false>(k, n_beams, st);
+#else
+    return k.u_held ? one_held<LV, LOGNW, GRAV, EM, true>(k, n_beams, st) : one_held<LV, LOGNW, GRAV, EM, false>(k, n_beams, st);
+#endif
 }
 template <int LV, int LOGNW, bool GRAV, int EM>
 hipError_t one_stage(const KParams<T>& k, int n_groups, hipStream_t st) {

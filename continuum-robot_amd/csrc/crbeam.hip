@@ -683,7 +683,8 @@ int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 // cantilever's nearest-neighbour form.  The kernels live in crb_lean.hip (one translation unit per dtype).
 inline bool lean_eligible(const crb_plan* p, const void* held) {
     const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
-    return (!grav || p->canonical_gravity) && !held && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
+    (void)held;   // (a held input has its own instantiation of the lean stepper)
+    return (!grav || p->canonical_gravity) && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
            p->levels >= 3 && p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr;
 }
 template <typename T>

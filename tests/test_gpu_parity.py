@@ -165,6 +165,34 @@ def test_held_force_and_pack_roundtrip():
     assert rel_err(ens.unpack_state().cpu().numpy(), ref) < 1e-10
 
 
+@pytest.mark.parametrize("n_e,kind,kw", [(64, "linear", dict(enable_gravity=True)),
+                                          (128, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True)),
+                                          (256, "mixed", dict(fluid_density=1000.0, enable_fluid=True))])
+def test_held_force_on_lean_size_beams(n_e, kind, kw, monkeypatch):
+    """A per-node input force held over the launch (zero-order-hold control) through the lean stepper's HELD
+    instantiation, against the oracle and against the general kernel."""
+    kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)] if kind == "mixed" else kind
+    cols = nitinol_columns(n_e, kinds)
+    ob = oracle_beam(cols, **kw)
+    n, B = ob.n, 3
+    rng = np.random.default_rng(n_e)
+    x0 = rng.normal(0, 1e-5, (B, 2 * n))
+    u = rng.normal(0, 1e-3, (B, n))       # (small: the shipped nonlinear element diverges under large axial loads)
+    steps = 60
+    ens = ensemble(cols, B, kw)
+    ens.set_state(x0)
+    ens.step(steps, 2e-5, held_force=u)
+    got = ens.unpack_state().cpu().numpy()
+    ref = np.array([ob.rk4_held(x0[b], 2e-5, steps, u[b]) for b in range(B)])
+    assert np.isfinite(ref).all()
+    assert rel_err(got, ref) < 1e-9
+    monkeypatch.setenv("CRB_DISABLE_LEAN", "1")
+    gen = ensemble(cols, B, kw)
+    gen.set_state(x0)
+    gen.step(steps, 2e-5, held_force=u)
+    assert rel_err(gen.unpack_state().cpu().numpy(), got) < 1e-11
+
+
 @pytest.mark.parametrize("n_e,B", [(1, 1), (2, 70), (10, 13), (63, 5), (65, 3), (130, 2), (300, 2), (600, 2), (1024, 1)])
 def test_ragged_sizes_and_partial_groups(n_e, B):
     """Beam sizes around the wavefront/workgroup boundaries, batch sizes that leave a group partly empty."""
