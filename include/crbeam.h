@@ -202,7 +202,9 @@ int crb_feedback_force(const crb_plan* plan, const void* xs, const void* gain, c
  * stage's generalised force u_stage[B][n_node][4] from xs (e.g. one GEMM over the whole ensemble) and
  * calls:   k = f(t_stage, xs, u_stage + impulse);  acc = (stage ? acc : 0) + w_stage * k;
  *          stage < 3: xs_next = x + c_stage * k;      stage == 3: x += dt/6 * acc.
- * Stage 0 passes xs == x.  x, xs, acc, xs_next: device [B][2][n_node][4]; xs_next may not alias xs. */
+ * Stage 0 passes xs == x.  x, xs, acc, xs_next: device [B][2][n_node][4]; xs_next may not alias xs.
+ * All state / force buffers of this header must be aligned to 32 bytes (a node record is read as one
+ * vector); hipMalloc and torch allocations are. */
 int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage,
                   int stage, double t_stage, double dt, const crb_input_desc* input, void* stream);
 
