@@ -18,7 +18,7 @@ out = sys.argv[1]
 tot, n = {}, {}
 for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "crb_feedback_kernel" not in row["Kernel_Name"]:
+        if "crb_feedback" not in row["Kernel_Name"]:
             continue
         c = row["Counter_Name"]
         tot[c] = tot.get(c, 0.0) + float(row["Counter_Value"]); n[c] = n.get(c, 0) + 1
