@@ -36,6 +36,10 @@ CONFIGS = {
     # name: (beams per GPU, elements, element type, force kwargs, random x0, default steps)
     "config3": dict(beams=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False,
                     label="4096 beams x 256 elem, nonlinear Euler-Bernoulli + fluid drag, fp64"),
+    # BASELINE config 4: the same ensemble in fp32 (batch-sharded across the node's GPUs); 200 steps by default,
+    # beyond which single precision drifts past 1e-5 from the fp64 oracle
+    "config4": dict(beams=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False, dtype="f32", steps=200,
+                    label="4096 beams x 256 elem, nonlinear Euler-Bernoulli + fluid drag, fp32"),
     "config2": dict(beams=1024, elems=64, kind="linear", drag=False, gravity=True, x0=True,
                     label="1024 beams x 64 elem, linear + gravity, fp64"),
     # LQR rollout ensemble (BASELINE config 5: 2048 beams/GPU): state feedback u = K(0 - x) at every RK4
@@ -61,10 +65,10 @@ def lqr_gain(ens):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=None, help="timed RK4 steps (default 1000; 200 for config4)")
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"], help="default: the config's (f64; config4: f32)")
     ap.add_argument("--launch-steps", type=int, default=100,
                     help="RK4 steps fused per launch (0 = all of --steps); warmup uses launches of the same size, so "
                          "every stepper launch of a run is identical and rocprof's per-kernel average is the launch time")
@@ -73,7 +77,13 @@ def parse():
                     help="after timing, compare EVERY beam of rank 0 with the oracle (open-loop configs; tens of CPU-seconds)")
     ap.add_argument("--hetero", action="store_true",
                     help="heterogeneous variant (SURVEY 8(d)): per-beam E, rho, r scaled by U(0.9, 1.1), seed 4321")
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.dtype is None:
+        args.dtype = cfg.get("dtype", "f64")
+    if args.steps is None:
+        args.steps = cfg.get("steps", 1000)
+    return args
 
 
 def cpu_baseline(cols, kw, n_elem, target_s=15.0):
