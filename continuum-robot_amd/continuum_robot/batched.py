@@ -276,17 +276,14 @@ class BeamEnsemble:
         gain       [n, 2n] LQR gain (reduced ordering, e.g. LinearQuadraticRegulator.compute_gain_matrix())
         reference  [B, 2n] or None (= regulation to 0)
         Stage-split path: per stage one GEMM over the whole ensemble, [B, 2n] x [2n, n] -- the fused
-        fp64-MFMA kernel crb_feedback_force (gather + GEMM + scatter; fp32 plans go through
-        torch.matmul) -- then one launch of the stage kernel (crb_rk4_stage).
+        MFMA kernel crb_feedback_force (gather + GEMM + scatter, in the plan's dtype) -- then one launch
+        of the stage kernel (crb_rk4_stage); the loop itself is crb_step_rk4_feedback.
         Note: the LQR loop is stiff (|lambda|max ~ 3e5 1/s for the Nitinol example): RK4 needs
         dt <= ~8e-6 s, not the 2e-5 s of the open-loop configs.
         """
         if t0 is not None:
             self.time = float(t0)
         K = self._dev(gain, (self.n, 2 * self.n))
-        fused = self.dtype == torch.float64
-        Kt = None if fused else K.t().contiguous()
-        u_buf = torch.zeros((self.n_beams, self.n_node, 4), dtype=self.dtype, device=self.device)
         ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
         desc = nat.InputDesc()
         desc.kind = nat.CRB_INPUT_NONE
@@ -300,40 +297,16 @@ class BeamEnsemble:
             desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, full // 3, full % 3
             desc.duration = float(impulse_duration)
             desc.amp = amp.data_ptr()
-        t, dt = self.time, float(dt)
-        if fused:   # the whole loop is one native call (crb_step_rk4_feedback issues every launch)
-            work = torch.empty((int(self._lib.crb_feedback_work_bytes(self.plan.h)),), dtype=torch.uint8, device=self.device)
-            t_end = C.c_double(0.0)
-            with torch.cuda.device(self.device):
-                nat.check(self._lib.crb_step_rk4_feedback(self.plan.h, self._ptr(self.state), t, dt, int(n_steps), self._ptr(K),
-                                                          self._ptr(ref), C.byref(desc), self._ptr(work), C.byref(t_end),
-                                                          self._stream()))
-            self._keep = [amp, K, ref, work]
-            self.time = float(t_end.value)
-            return self.time
-        acc = torch.empty_like(self.state)
-        bufs = (torch.empty_like(self.state), torch.empty_like(self.state))
+        # the whole loop is one native call (crb_step_rk4_feedback issues every launch)
+        work = torch.empty((int(self._lib.crb_feedback_work_bytes(self.plan.h)),), dtype=torch.uint8, device=self.device)
+        t_end = C.c_double(0.0)
         with torch.cuda.device(self.device):
-            stream = self._stream()
-            for _ in range(int(n_steps)):
-                th, t1 = t + 0.5 * dt, t + dt
-                cur = self.state
-                for s, ts in enumerate((t, th, th, t1)):
-                    if fused:
-                        nat.check(self._lib.crb_feedback_force(self.plan.h, self._ptr(cur), self._ptr(K), self._ptr(ref),
-                                                               self._ptr(u_buf), stream))
-                        u_dev = u_buf
-                    else:
-                        xr = self.unpack_state(cur)
-                        u_dev = self.pack_vec((-xr if ref is None else ref - xr) @ Kt)
-                    nxt = bufs[s & 1]
-                    nat.check(self._lib.crb_rk4_stage(self.plan.h, self._ptr(self.state), self._ptr(cur), self._ptr(acc),
-                                                      self._ptr(nxt), self._ptr(u_dev), s, ts, dt, C.byref(desc), stream))
-                    cur = nxt
-                t = t1
-        self._keep = [amp, acc, bufs, K, Kt, ref, u_buf]
-        self.time = t
-        return t
+            nat.check(self._lib.crb_step_rk4_feedback(self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps),
+                                                      self._ptr(K), self._ptr(ref), C.byref(desc), self._ptr(work),
+                                                      C.byref(t_end), self._stream()))
+        self._keep = [amp, K, ref, work]
+        self.time = float(t_end.value)
+        return self.time
 
     def gather(self, node: int, param: str, velocity: bool = False) -> torch.Tensor:
         out = torch.empty((self.n_beams,), dtype=self.dtype, device=self.device)

@@ -18,12 +18,25 @@ namespace crb {
 // (lane l -> row l&15, k = kk + (l>>4)) then touch every bank exactly once.
 // MFMA lane maps (MI355X guide): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
 // D: col j = l&15, row i = (l>>4) + 4*reg.
-typedef double crb_d4 __attribute__((ext_vector_type(4)));
+// the MFMA of each dtype: A / B fragments are one value per lane (A[i = lane & 15][k = lane >> 4]) for both,
+// the C/D row of accumulator register `reg` differs (cdna_hip_programming.md, 'Fragment layout')
+template <typename T> struct MfmaOps;
+template <> struct MfmaOps<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct MfmaOps<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+template <typename T>
 struct FeedbackParams {
-    const double* xs;       // [B][2][n_node][4]
-    const double* ref;      // [B][2n] reduced, or nullptr (= 0)
-    const double* gain;     // [n][2n] row-major
-    double* u;              // [B][n_node][4]; only free-DOF entries are written
+    const T* xs;       // [B][2][n_node][4]
+    const T* ref;      // [B][2n] reduced, or nullptr (= 0)
+    const T* gain;     // [n][2n] row-major
+    T* u;              // [B][n_node][4]; only free-DOF entries are written
     const int32_t* col_off; // [2n] offset of reduced state index j inside a beam's state record
     const int32_t* row_off; // [n]  offset of reduced position index i inside a beam's force record
     int B, n, n2;           // n2 = 2n
@@ -39,14 +52,15 @@ struct FeedbackParams {
 #ifndef CRB_GEMM_SCHED
 #define CRB_GEMM_SCHED 0
 #endif
-template <int BM, int BN, int BK, int WR, bool HAS_REF>
-__global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams p) {
+template <typename T, int BM, int BN, int BK, int WR, bool HAS_REF>
+__global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<T> p) {
+    typedef typename MfmaOps<T>::acc_t crb_d4;
     constexpr int WC = 4 / WR, TM = BM / (16 * WR), TN = BN / (16 * WC), LD = BK + 2;
     constexpr int QA = BM * BK / 256, QB = BN * BK / 256, RSTEP = 256 / BK;
     static_assert(BM % (16 * WR) == 0 && BN % (16 * WC) == 0 && 256 % BK == 0 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
-    double* const As = reinterpret_cast<double*>(crb_smem);          // [2][BM * LD]
-    double* const Bs = As + 2 * BM * LD;                             // [2][BN * LD]
+    T* const As = reinterpret_cast<T*>(crb_smem);          // [2][BM * LD]
+    T* const Bs = As + 2 * BM * LD;                             // [2][BN * LD]
     int32_t* const coff_s = reinterpret_cast<int32_t*>(Bs + 2 * BN * LD);  // [n2]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -56,13 +70,13 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = crb_d4{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < TN; ++b) acc[a][b] = crb_d4{T(0), T(0), T(0), T(0)};
 
     // loader: this thread fetches column lk of rows lr + RSTEP*q of both tiles
     const int lk = t & (BK - 1), lr = t / BK;
-    const double* xrow[QA];
-    const double* rrow[QA];
-    const double* grow[QB];
+    const T* xrow[QA];
+    const T* rrow[QA];
+    const T* grow[QB];
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
         const int b = m0 + lr + RSTEP * q;
@@ -83,12 +97,12 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
     // zeroed on the gain side only, by a multiplication (a per-lane select on k would come back as a
     // branch and split the scheduling region).  Without a reference the A tile holds +x and the sign goes
     // into the epilogue: the state goes from global memory to LDS untouched.
-    struct Regs { double xa[QA], ra[QA], gb[QB]; double kmask; };
+    struct Regs { T xa[QA], ra[QA], gb[QB]; T kmask; };
     Regs R0, R1;
     auto fetch = [&](Regs& R, int k0) {
         const int k = k0 + lk;
         const bool kok = k < p.n2;
-        R.kmask = kok ? 1.0 : 0.0;
+        R.kmask = kok ? T(1) : T(0);
         const int kc = kok ? k : 0;
         const int coff = coff_s[kc];
 #pragma unroll
@@ -100,8 +114,8 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
         for (int q = 0; q < QB; ++q) R.gb[q] = grow[q][kc];
     };
     auto stash_piece = [&](const Regs& R, int st, int piece) {   // element `piece` of the QA + QB this thread stores
-        double* A = As + st * BM * LD;
-        double* Bt = Bs + st * BN * LD;
+        T* A = As + st * BM * LD;
+        T* Bt = Bs + st * BN * LD;
         if (piece < QA) {
             const int q = piece;
             A[(lr + RSTEP * q) * LD + lk] = HAS_REF ? R.ra[q] - R.xa[q] : R.xa[q];
@@ -127,9 +141,9 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
         // (no conditions here: past the end fetch() reads clamped addresses and the stash fills an LDS stage
         //  that nobody reads any more -- one basic block, so that the interleave below can be enforced)
         fetch(Rnxt, kbase + (sidx + 2) * BK);
-        const double* Aw = As + st * BM * LD + (wm + (lane & 15)) * LD + (lane >> 4);
-        const double* Bw = Bs + st * BN * LD + (wn + (lane & 15)) * LD + (lane >> 4);
-        double af[2][TM], bf[2][TN];   // fragments of sub-step kk+4 are read while the MFMAs of sub-step kk run
+        const T* Aw = As + st * BM * LD + (wm + (lane & 15)) * LD + (lane >> 4);
+        const T* Bw = Bs + st * BN * LD + (wn + (lane & 15)) * LD + (lane >> 4);
+        T af[2][TM], bf[2][TN];   // fragments of sub-step kk+4 are read while the MFMAs of sub-step kk run
 #pragma unroll
         for (int a = 0; a < TM; ++a) af[0][a] = Aw[16 * a * LD];
 #pragma unroll
@@ -147,7 +161,7 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = MfmaOps<T>::run(af[cur][a], bf[cur][b], acc[a][b]);
 #pragma unroll
             for (int i = 0; i < PPS; ++i) stash_piece(Rcur, st ^ 1, (kk >> 2) * PPS + i);
         }
@@ -180,10 +194,10 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
             const int roff = p.row_off[i];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int beam = m0 + wm + 16 * a + (lane >> 4) + 4 * reg;
+                const int beam = m0 + wm + 16 * a + MfmaOps<T>::row(lane, reg);
                 if (beam < p.B) {
-                    const double v = HAS_REF ? acc[a][b][reg] : -acc[a][b][reg];
-                    double* dst = p.u + size_t(beam) * p.u_stride + roff;
+                    const T v = HAS_REF ? acc[a][b][reg] : -acc[a][b][reg];
+                    T* dst = p.u + size_t(beam) * p.u_stride + roff;
                     if (gridDim.z > 1) unsafeAtomicAdd(dst, v);
                     else *dst = v;
                 }
@@ -198,14 +212,15 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams 
 // One barrier per K step, taken by both roles.  In-kernel cycle stamps at 2048 x 768 x 384 (64 x 48 tiles,
 // BK 64, 12 K steps): prologue 7.3k cycles (offset table, first tile), per step 3.6k cycles for 48 MFMAs
 // (75 each, 64 = pipe-bound) + 0.4-0.7k at the barrier; 32.7 us against 34.1 us for crb_feedback_kernel.
-template <int BN, int BK, bool HAS_REF>
-__global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackParams p) {
+template <typename T, int BN, int BK, bool HAS_REF>
+__global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackParams<T> p) {
+    typedef typename MfmaOps<T>::acc_t crb_d4;
     constexpr int BM = 64, TN = BN / 16, LD = BK + 2;
     constexpr int QA = BM * BK / 256, QB = BN * BK / 256, RSTEP = 256 / BK;
     static_assert(BN % 16 == 0 && 256 % BK == 0 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
-    double* const As = reinterpret_cast<double*>(crb_smem);          // [2][BM * LD]
-    double* const Bs = As + 2 * BM * LD;                             // [2][BN * LD]
+    T* const As = reinterpret_cast<T*>(crb_smem);          // [2][BM * LD]
+    T* const Bs = As + 2 * BM * LD;                             // [2][BN * LD]
     int32_t* const coff_s = reinterpret_cast<int32_t*>(Bs + 2 * BN * LD);  // [n2]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -218,9 +233,9 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
         __builtin_amdgcn_s_setprio(0);
         const int lt = t - 256;
         const int lk = lt & (BK - 1), lr = lt / BK;
-        const double* xrow[QA];
-        const double* rrow[QA];
-        const double* grow[QB];
+        const T* xrow[QA];
+        const T* rrow[QA];
+        const T* grow[QB];
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             const int b = m0 + lr + RSTEP * q;
@@ -233,12 +248,12 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
             const int i = n0 + lr + RSTEP * q;
             grow[q] = p.gain + size_t(i < p.n ? i : p.n - 1) * p.n2;
         }
-        struct Regs { double xa[QA], ra[QA], gb[QB]; double kmask; };
+        struct Regs { T xa[QA], ra[QA], gb[QB]; T kmask; };
         Regs R0, R1;
         auto fetch = [&](Regs& R, int k0) {   // unconditional loads (clamped), K tail zeroed on the gain side
             const int k = k0 + lk;
             const bool kok = k < p.n2;
-            R.kmask = kok ? 1.0 : 0.0;
+            R.kmask = kok ? T(1) : T(0);
             const int kc = kok ? k : 0;
             const int coff = coff_s[kc];
 #pragma unroll
@@ -250,8 +265,8 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
             for (int q = 0; q < QB; ++q) R.gb[q] = grow[q][kc];
         };
         auto stash = [&](const Regs& R, int st) {
-            double* A = As + st * BM * LD;
-            double* Bt = Bs + st * BN * LD;
+            T* A = As + st * BM * LD;
+            T* Bt = Bs + st * BN * LD;
 #pragma unroll
             for (int q = 0; q < QA; ++q) A[(lr + RSTEP * q) * LD + lk] = HAS_REF ? R.ra[q] - R.xa[q] : R.xa[q];
 #pragma unroll
@@ -277,13 +292,13 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
     __builtin_amdgcn_s_setprio(2);
     crb_d4 acc[TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) acc[b] = crb_d4{0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < TN; ++b) acc[b] = crb_d4{T(0), T(0), T(0), T(0)};
     __syncthreads();                           // stage 0 ready
     for (int sidx = 0; sidx < nsteps; ++sidx) {
         const int st = sidx & 1;
-        const double* Aw = As + st * BM * LD + (16 * wave + (lane & 15)) * LD + (lane >> 4);
-        const double* Bw = Bs + st * BN * LD + (lane & 15) * LD + (lane >> 4);
-        double af[2], bf[2][TN];               // fragments of sub-step kk+4 are read while the MFMAs of sub-step kk run
+        const T* Aw = As + st * BM * LD + (16 * wave + (lane & 15)) * LD + (lane >> 4);
+        const T* Bw = Bs + st * BN * LD + (lane & 15) * LD + (lane >> 4);
+        T af[2], bf[2][TN];               // fragments of sub-step kk+4 are read while the MFMAs of sub-step kk run
         af[0] = Aw[0];
 #pragma unroll
         for (int b = 0; b < TN; ++b) bf[0][b] = Bw[16 * b * LD];
@@ -296,7 +311,7 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
                 for (int b = 0; b < TN; ++b) bf[nxt][b] = Bw[16 * b * LD + kk + 4];
             }
 #pragma unroll
-            for (int b = 0; b < TN; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur], bf[cur][b], acc[b], 0, 0, 0);
+            for (int b = 0; b < TN; ++b) acc[b] = MfmaOps<T>::run(af[cur], bf[cur][b], acc[b]);
         }
         __syncthreads();
     }
@@ -308,14 +323,14 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
         const int roff = p.row_off[i];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int beam = m0 + 16 * wave + (lane >> 4) + 4 * reg;
+            const int beam = m0 + 16 * wave + MfmaOps<T>::row(lane, reg);
             if (beam < p.B) p.u[size_t(beam) * p.u_stride + roff] = HAS_REF ? acc[b][reg] : -acc[b][reg];
         }
     }
 }
-template <int BM, int BN, int BK>
+template <typename T, int BM, int BN, int BK>
 __host__ __device__ constexpr size_t feedback_lds_bytes(int n2) {
-    return size_t(2) * (BM + BN) * (BK + 2) * sizeof(double) + size_t(n2) * sizeof(int32_t);
+    return size_t(2) * (BM + BN) * (BK + 2) * sizeof(T) + size_t(n2) * sizeof(int32_t);
 }
 
 

@@ -877,7 +877,7 @@ static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc,
 
 extern "C" size_t crb_feedback_work_bytes(const crb_plan* p) {
     if (!p) return 0;
-    const size_t state = size_t(p->B) * 2 * p->n_node * 4 * sizeof(double), force = state / 2;
+    const size_t state = size_t(p->B) * 2 * p->n_node * 4 * (p->dtype == CRB_F64 ? sizeof(double) : sizeof(float)), force = state / 2;
     return 3 * state + force + 256;   // + the device clock of the replayed step
 }
 
@@ -902,9 +902,8 @@ extern "C" int crb_step_rk4_feedback(const crb_plan* p, void* x, double t0, doub
                                      const void* ref, const crb_input_desc* in, void* work, double* t_end, void* stream) {
     if (int rc = need_device(p, "crb_step_rk4_feedback")) return rc;
     if (!x || !gain || !work) return fail(CRB_EINVAL, "crb_step_rk4_feedback: null pointer");
-    if (p->dtype != CRB_F64) return fail(CRB_EUNSUPPORTED, "crb_step_rk4_feedback: fp64 plans only");
     if (n_steps < 0 || !(dt > 0)) return fail(CRB_EINVAL, "crb_step_rk4_feedback: n_steps >= 0 and dt > 0 required");
-    const size_t state = size_t(p->B) * 2 * p->n_node * 4 * sizeof(double);
+    const size_t state = size_t(p->B) * 2 * p->n_node * 4 * (p->dtype == CRB_F64 ? sizeof(double) : sizeof(float));
     char* w = static_cast<char*>(work);
     void* acc = w;
     void* bufs[2] = {w + state, w + 2 * state};
@@ -1081,65 +1080,68 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
 }
 
 namespace {
-template <int BM, int BN, int BK, int WR>
-int launch_feedback_tile(const FeedbackParams& f, int ksplit, hipStream_t st) {
+template <typename T, int BM, int BN, int BK, int WR>
+int launch_feedback_tile(const FeedbackParams<T>& f, int ksplit, hipStream_t st) {
     const dim3 grid((f.B + BM - 1) / BM, (f.n + BN - 1) / BN, ksplit);
-    const size_t smem = feedback_lds_bytes<BM, BN, BK>(f.n2);
-    if (ksplit > 1) HIP_TRY(hipMemsetAsync(f.u, 0, size_t(f.B) * f.u_stride * sizeof(double), st));
+    const size_t smem = feedback_lds_bytes<T, BM, BN, BK>(f.n2);
+    if (ksplit > 1) HIP_TRY(hipMemsetAsync(f.u, 0, size_t(f.B) * f.u_stride * sizeof(T), st));
     if (f.ref) {
-        if (int rc = allow_lds(crb_feedback_kernel<BM, BN, BK, WR, true>, smem)) return rc;
-        hipLaunchKernelGGL((crb_feedback_kernel<BM, BN, BK, WR, true>), grid, dim3(256), smem, st, f);
+        if (int rc = allow_lds(crb_feedback_kernel<T, BM, BN, BK, WR, true>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_kernel<T, BM, BN, BK, WR, true>), grid, dim3(256), smem, st, f);
     } else {
-        if (int rc = allow_lds(crb_feedback_kernel<BM, BN, BK, WR, false>, smem)) return rc;
-        hipLaunchKernelGGL((crb_feedback_kernel<BM, BN, BK, WR, false>), grid, dim3(256), smem, st, f);
+        if (int rc = allow_lds(crb_feedback_kernel<T, BM, BN, BK, WR, false>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_kernel<T, BM, BN, BK, WR, false>), grid, dim3(256), smem, st, f);
     }
     return CRB_OK;
 }
-template <int BN, int BK>
-int launch_feedback_ws(const FeedbackParams& f, hipStream_t st) {
+template <typename T, int BN, int BK>
+int launch_feedback_ws(const FeedbackParams<T>& f, hipStream_t st) {
     const dim3 grid((f.B + 63) / 64, (f.n + BN - 1) / BN);
-    const size_t smem = feedback_lds_bytes<64, BN, BK>(f.n2);
+    const size_t smem = feedback_lds_bytes<T, 64, BN, BK>(f.n2);
     if (f.ref) {
-        if (int rc = allow_lds(crb_feedback_ws_kernel<BN, BK, true>, smem)) return rc;
-        hipLaunchKernelGGL((crb_feedback_ws_kernel<BN, BK, true>), grid, dim3(512), smem, st, f);
+        if (int rc = allow_lds(crb_feedback_ws_kernel<T, BN, BK, true>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_ws_kernel<T, BN, BK, true>), grid, dim3(512), smem, st, f);
     } else {
-        if (int rc = allow_lds(crb_feedback_ws_kernel<BN, BK, false>, smem)) return rc;
-        hipLaunchKernelGGL((crb_feedback_ws_kernel<BN, BK, false>), grid, dim3(512), smem, st, f);
+        if (int rc = allow_lds(crb_feedback_ws_kernel<T, BN, BK, false>, smem)) return rc;
+        hipLaunchKernelGGL((crb_feedback_ws_kernel<T, BN, BK, false>), grid, dim3(512), smem, st, f);
     }
     return CRB_OK;
 }
 // tile: 0 = choose.  Large ensembles: 64 x 48 outputs per workgroup, wave-specialised (one workgroup per CU
 // and the fewest L2 reads at the config-5 shape: 32.7 us at 2048 x 768 x 384 against 37 us for 32 x 32);
 // small ensembles: 32 x 32 for the larger grid.  CRB_FEEDBACK_TILE=48|32 forces one (tests cover both).
-int launch_feedback(int tile, const FeedbackParams& f, hipStream_t st) {
+template <typename T>
+int launch_feedback(int tile, const FeedbackParams<T>& f, hipStream_t st) {
     const long wide_groups = long((f.B + 63) / 64) * ((f.n + 47) / 48);
-    const bool wide_fits = feedback_lds_bytes<64, 48, 64>(f.n2) <= size_t(160) * 1024;
+    const bool wide_fits = feedback_lds_bytes<T, 64, 48, 64>(f.n2) <= size_t(160) * 1024;
     if (tile == 0) tile = (wide_groups >= 192 && wide_fits) ? 48 : 32;
-    if (tile == 48 && wide_fits) return launch_feedback_ws<48, 64>(f, st);
-    return launch_feedback_tile<32, 32, 32, 2>(f, 1, st);
+    if (tile == 48 && wide_fits) return launch_feedback_ws<T, 48, 64>(f, st);
+    return launch_feedback_tile<T, 32, 32, 32, 2>(f, 1, st);
+}
+template <typename T>
+int feedback_force_impl(const crb_plan* p, const void* xs, const void* gain, const void* ref, void* u, void* stream) {
+    FeedbackParams<T> f;
+    f.xs = static_cast<const T*>(xs);
+    f.ref = static_cast<const T*>(ref);
+    f.gain = static_cast<const T*>(gain);
+    f.u = static_cast<T*>(u);
+    f.col_off = p->d_col_off;
+    f.row_off = p->d_row_off;
+    f.B = p->B; f.n = p->n_free; f.n2 = 2 * p->n_free;
+    f.x_stride = size_t(2) * p->n_node * 4;
+    f.u_stride = size_t(p->n_node) * 4;
+    const char* force = std::getenv("CRB_FEEDBACK_TILE");
+    if (int rc = launch_feedback<T>(force ? std::atoi(force) : 0, f, static_cast<hipStream_t>(stream))) return rc;
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
 }
 }  // namespace
 
 extern "C" int crb_feedback_force(const crb_plan* p, const void* xs, const void* gain, const void* ref, void* u, void* stream) {
     if (int rc = need_device(p, "crb_feedback_force")) return rc;
     if (!xs || !gain || !u) return fail(CRB_EINVAL, "crb_feedback_force: null pointer");
-    if (p->dtype != CRB_F64) return fail(CRB_EUNSUPPORTED, "crb_feedback_force: fp64 plans only");
-    FeedbackParams f;
-    f.xs = static_cast<const double*>(xs);
-    f.ref = static_cast<const double*>(ref);
-    f.gain = static_cast<const double*>(gain);
-    f.u = static_cast<double*>(u);
-    f.col_off = p->d_col_off;
-    f.row_off = p->d_row_off;
-    f.B = p->B; f.n = p->n_free; f.n2 = 2 * p->n_free;
-    f.x_stride = size_t(2) * p->n_node * 4;
-    f.u_stride = size_t(p->n_node) * 4;
-    hipStream_t fst = static_cast<hipStream_t>(stream);
-    const char* force = std::getenv("CRB_FEEDBACK_TILE");
-    const int tile = force ? std::atoi(force) : 0;
-    if (int rc = launch_feedback(tile, f, fst)) return rc;
-    HIP_TRY(hipGetLastError());
-    return CRB_OK;
+    return p->dtype == CRB_F64 ? feedback_force_impl<double>(p, xs, gain, ref, u, stream)
+                               : feedback_force_impl<float>(p, xs, gain, ref, u, stream);
 }
 
 static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage, int stage,

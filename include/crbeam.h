@@ -189,8 +189,9 @@ int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, 
                         const crb_record_desc* rec, double eval_t0, double eval_dt, int n_eval, void* stream);
 
 /* Feedback force of a whole ensemble, u = K (r - x) (FullStateLinear.compute_input,
- * control/full_state_linear.py:81; loop of examples/lqr_control.py:95-111), as one fp64-MFMA GEMM with the
- * gather from the state layout and the scatter into the force layout fused in (fp64 plans only).
+ * control/full_state_linear.py:81; loop of examples/lqr_control.py:95-111), as one MFMA GEMM in the plan's dtype
+ * (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32) with the gather from the state layout and the scatter into
+ * the force layout fused in.
  *   xs   device [B][2][n_node][4]           gain  device [n][2n] row-major, reduced ordering
  *   ref  device [B][2n] reduced or NULL=0   u     device [B][n_node][4]: free-DOF entries are
  *                                                  overwritten, the rest must already be zero */
@@ -210,7 +211,7 @@ int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void
 
 /* The closed loop of examples/lqr_control.py:95-125 as ONE call: n_steps RK4 steps with u = K (r - x)
  * re-evaluated at every stage (crb_feedback_force, then crb_rk4_stage), all launches issued from here
- * (fp64 plans).  work: device scratch of crb_feedback_work_bytes(plan) bytes (three state-sized buffers and
+ * (either dtype).  work: device scratch of crb_feedback_work_bytes(plan) bytes (three state-sized buffers and
  * one force-sized buffer and the device clock; contents need not be initialised).  Returns the accumulated clock
  * in *t_end.  CRB_USE_GRAPH=1 in the environment replays one captured step as a hipGraph on a stream of the
  * plan's own (ordered after / before the caller's stream by events). */

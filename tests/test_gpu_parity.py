@@ -668,9 +668,6 @@ def test_native_feedback_rollout_entry_point_contract():
     assert lib.crb_step_rk4_feedback(ens.plan.h, vp(ens.state), 0.0, dt, steps, None, None, None, vp(work), C.byref(t_end), None) != 0
     assert b"null pointer" in lib.crb_last_error()
     assert lib.crb_step_rk4_feedback(ens.plan.h, vp(ens.state), 0.0, -1.0, steps, vp(gain), None, None, vp(work), C.byref(t_end), None) != 0
-    f32 = ensemble(cols, B, dict(enable_gravity=True), dtype=torch.float32)
-    assert lib.crb_step_rk4_feedback(f32.plan.h, vp(f32.state), 0.0, dt, 1, vp(gain), None, None, vp(work), C.byref(t_end), None) != 0
-    assert b"fp64 plans only" in lib.crb_last_error()
     # the rollout, against the stage-by-stage loop
     nat.check(lib.crb_step_rk4_feedback(ens.plan.h, vp(ens.state), 0.25, dt, steps, vp(gain), None, None, vp(work),
                                         C.byref(t_end), None))
@@ -735,3 +732,43 @@ def test_adaptive_rk45_lean_rhs_equals_general_rhs(n_e, kind, monkeypatch):
         if dtype == torch.float64:
             assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
         assert rel_err(out[0][2], out[1][2]) < tol
+
+
+@pytest.mark.parametrize("tile", ["32", "48"])
+@pytest.mark.parametrize("n_e,B", [(24, 70), (128, 130)])
+def test_fp32_feedback_force_and_rollout(n_e, B, tile, monkeypatch):
+    """fp32 plans: crb_feedback_force on v_mfma_f32_16x16x4_f32 (its C/D row map differs from the fp64
+    instruction's) against torch.matmul, and the native closed-loop rollout against the fp64 one."""
+    import ctypes as C
+
+    from continuum_robot import _native as nat
+
+    monkeypatch.setenv("CRB_FEEDBACK_TILE", tile)
+    cols = nitinol_columns(n_e, "linear")
+    e32 = ensemble(cols, B, dict(enable_gravity=True), dtype=torch.float32)
+    n = e32.n
+    g = torch.Generator(device="cpu").manual_seed(n_e)
+    K = torch.randn((n, 2 * n), generator=g, dtype=torch.float32).to(e32.device)
+    X = torch.randn((B, 2 * n), generator=g, dtype=torch.float32).to(e32.device)
+    R = torch.randn((B, 2 * n), generator=g, dtype=torch.float32).to(e32.device)
+    xs = e32.pack_state(X)
+    for ref in (None, R):
+        u = torch.zeros((B, e32.n_node, 4), dtype=torch.float32, device=e32.device)
+        nat.check(nat.load().crb_feedback_force(e32.plan.h, C.c_void_p(xs.data_ptr()), C.c_void_p(K.data_ptr()),
+                                                C.c_void_p(ref.data_ptr()) if ref is not None else None,
+                                                C.c_void_p(u.data_ptr()), None))
+        want = ((ref if ref is not None else 0) - X).double() @ K.double().t()
+        got = e32.unpack_vec(u).double()
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 5e-6
+        assert float(u[..., 3].abs().max()) == 0.0
+    # rollout: fp32 tracks fp64 (small gain, short horizon)
+    rng = np.random.default_rng(n_e)
+    gain = rng.normal(0.0, 2e-2, (n, 2 * n))
+    x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
+    outs = []
+    for dtype in (torch.float64, torch.float32):
+        e = ensemble(cols, B, dict(enable_gravity=True), dtype=dtype)
+        e.set_state(x0)
+        e.step_feedback(20, 2e-5, gain, impulse_amp=np.full(B, 0.05))
+        outs.append(e.unpack_state().double().cpu().numpy())
+    assert rel_err(outs[1], outs[0]) < 2e-3
