@@ -131,6 +131,10 @@ class BeamEnsemble:
             nat.check(self._lib.crb_unpack_vec(self.plan.h, self._ptr(v), self._ptr(out), self._stream()))
         return out
 
+    def unpack_snapshots(self, snaps: torch.Tensor) -> torch.Tensor:
+        """[n_rec, B, 2, n_node, 4] snapshots of step(..., record="all") -> reduced [n_rec, B, 2n] (sol.y ordering)."""
+        return torch.stack([self.unpack_state(snaps[k]) for k in range(snaps.shape[0])])
+
     def set_state(self, x_red, time: float = 0.0) -> None:
         self.state = self.pack_state(x_red)
         self.time = float(time)
@@ -172,7 +176,8 @@ class BeamEnsemble:
         held_force     reduced [B, n] generalised force held constant over the call
         record         (node, 'u'|'w'|'phi'|'du_dt'|'dw_dt'|'dphi_dt'): sample that DOF on the device after
                        every ``record_every``-th step (the t_eval output of the reference's solve_ivp
-                       calls); the call then returns (clock, samples[B, n_steps // record_every])
+                       calls); the call then returns (clock, samples[B, n_steps // record_every]).
+                       "all": whole-state snapshots instead, (clock, snaps[n_rec, B, 2, n_node, 4])
         Returns the clock after the call (accumulated by addition, as the oracle does).
         """
         if t0 is not None:
@@ -196,7 +201,14 @@ class BeamEnsemble:
             keep.append(held)
         t_end = C.c_double(0.0)
         rec, samples = None, None
-        if record is not None:
+        if isinstance(record, str) and record == "all":
+            # whole-state snapshots (every DOF of the reference's sol.y on the t_eval grid): device layout
+            # [n_rec, B, 2, n_node, 4]; reduced ordering through unpack_snapshots()
+            samples = torch.zeros((int(n_steps) // int(record_every),) + tuple(self.state.shape), dtype=self.dtype,
+                                  device=self.device)
+            rec = nat.RecordDesc(0, -1, 0, int(record_every), samples.data_ptr())
+            keep.append(samples)
+        elif record is not None:
             node, param = record
             vel = param.startswith("d") and param.endswith("_dt")
             samples = torch.zeros((self.n_beams, int(n_steps) // int(record_every)), dtype=self.dtype, device=self.device)

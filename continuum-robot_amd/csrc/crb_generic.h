@@ -62,7 +62,8 @@ struct KParams {
     const double* t_dev;       // MODE_STAGE: device clock of the step being taken (hipGraph replay: the launch
                                // arguments must not change from step to step); nullptr = t0 holds the stage time
     T* rec_out;                // MODE_STEP: [B][n_rec] strided record of one DOF, or nullptr
-    int rec_slot, rec_comp;    // recording thread (slot) and component 0..5 of {q, v}
+    int rec_slot, rec_comp;    // recording thread (slot; REC_ALL_SLOTS = whole-state snapshots
+                               // [n_rec][B][2][n_node][4]) and component 0..5 of {q, v}
     int rec_every, rec_n;
     // per-beam coefficient mode (heterogeneous ensembles): table offsets per beam, in elements; 0 = shared
     size_t slot_stride, lv_stride, fin_stride;
@@ -76,6 +77,7 @@ struct KParams {
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
+constexpr int REC_ALL_SLOTS = -2;
 // stage time of the stage-split stepper: passed by value, or derived from the device clock with the host
 // loop's own operations (t, t + dt/2, t + dt/2, t + dt, each a single IEEE addition)
 template <typename T>
@@ -417,11 +419,20 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
 #pragma unroll
         for (int c = 0; c < 6; ++c) x[c] += dt6 * acc[c];
         tc = t_full;
-        if (p.rec_out && valid && tp.j == p.rec_slot && (step + 1) % p.rec_every == 0) {
-            T val = x[0];
+        if (p.rec_out && valid && (step + 1) % p.rec_every == 0) {
+            const size_t k = size_t((step + 1) / p.rec_every - 1);
+            if (p.rec_slot == REC_ALL_SLOTS) {   // whole-state snapshot k
+                T* snap = p.rec_out + k * size_t(p.B) * 2 * plane + xoff;
 #pragma unroll
-            for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? x[c] : val;
-            p.rec_out[size_t(beam) * p.rec_n + (step + 1) / p.rec_every - 1] = val;
+                for (int c = 0; c < 3; ++c) { snap[c] = x[c]; snap[plane + c] = x[3 + c]; }
+                snap[3] = T(0);
+                snap[plane + 3] = T(0);
+            } else if (tp.j == p.rec_slot) {
+                T val = x[0];
+#pragma unroll
+                for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? x[c] : val;
+                p.rec_out[size_t(beam) * p.rec_n + k] = val;
+            }
         }
     }
     if (valid) {

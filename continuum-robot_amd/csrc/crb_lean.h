@@ -458,11 +458,19 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 #pragma unroll
         for (int c = 0; c < 3; ++c) { xq[c] = sq[c]; xv[c] = sv[c]; }
         tc = t_full;
-        if (p.rec_out && valid && j == p.rec_slot && (step + 1) % p.rec_every == 0) {
-            T val = xq[0];
+        if (p.rec_out && valid && (step + 1) % p.rec_every == 0) {
+            const size_t k = size_t((step + 1) / p.rec_every - 1);
+            if (p.rec_slot == REC_ALL_SLOTS) {   // whole-state snapshot k: every thread stores its node's two records
+                typedef T rec4 __attribute__((ext_vector_type(4)));
+                T* snap = p.rec_out + k * size_t(p.B) * 2 * plane + xoff;
+                *reinterpret_cast<rec4*>(snap) = rec4{xq[0], xq[1], xq[2], T(0)};
+                *reinterpret_cast<rec4*>(snap + plane) = rec4{xv[0], xv[1], xv[2], T(0)};
+            } else if (j == p.rec_slot) {
+                T val = xq[0];
 #pragma unroll
-            for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? (c < 3 ? xq[c] : xv[c - 3]) : val;
-            p.rec_out[size_t(beam) * p.rec_n + (step + 1) / p.rec_every - 1] = val;
+                for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? (c < 3 ? xq[c] : xv[c - 3]) : val;
+                p.rec_out[size_t(beam) * p.rec_n + k] = val;
+            }
         }
     }
     if (valid) {

@@ -810,7 +810,11 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     if (int rc = need_device(p, "crb_step_rk4")) return rc;
     int rec_slot = -1, rec_comp = 0, rec_every = 1, rec_n = 0;
     void* rec_out = nullptr;
-    if (rec) {
+    if (rec && rec->node == CRB_RECORD_ALL) {   // whole-state snapshots
+        if (rec->every < 1 || !rec->out) return fail(CRB_EINVAL, "crb_step_rk4_rec: bad record description");
+        rec_n = n_steps / rec->every;
+        if (rec_n > 0) { rec_slot = REC_ALL_SLOTS; rec_every = rec->every; rec_out = rec->out; }
+    } else if (rec) {
         if (rec->plane < 0 || rec->plane > 1 || rec->node < 0 || rec->node >= p->n_node || rec->dof < 0 || rec->dof > 2 ||
             rec->every < 1 || !rec->out)
             return fail(CRB_EINVAL, "crb_step_rk4_rec: bad record description");

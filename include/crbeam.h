@@ -100,6 +100,9 @@ typedef struct crb_input_desc {
  * (tip displacement, lqr_control.py:168; example_utilities.py:173-205).  After every `every`-th step
  * out[b][k] = x[b][plane][node][dof], k = (step+1)/every - 1; out holds floor(n_steps/every)
  * values per beam (device, plan dtype). */
+#define CRB_RECORD_ALL (-1) /* node = CRB_RECORD_ALL: whole-state snapshots (every DOF of sol.y on the t_eval grid,
+                             * what examples/example_utilities.py:173-205 reads beam shapes from): out is device
+                             * [floor(n_steps/every)][B][2][n_node][4], zero-initialised by the caller */
 typedef struct crb_record_desc {
     int32_t plane;   /* 0 position, 1 velocity */
     int32_t node;

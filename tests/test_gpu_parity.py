@@ -772,3 +772,25 @@ def test_fp32_feedback_force_and_rollout(n_e, B, tile, monkeypatch):
         e.step_feedback(20, 2e-5, gain, impulse_amp=np.full(B, 0.05))
         outs.append(e.unpack_state().double().cpu().numpy())
     assert rel_err(outs[1], outs[0]) < 2e-3
+
+
+@pytest.mark.parametrize("n_e,kw", [(12, dict(enable_gravity=True)),                       # general kernel, several beams per wave
+                                    (128, dict(fluid_density=1000.0, enable_fluid=True))])  # lean stepper
+def test_whole_state_snapshots_equal_chunked_stepping(n_e, kw):
+    """step(..., record="all"): snapshots of the whole state every k steps -- the reference's sol.y for every
+    DOF on a t_eval grid (example_utilities.py:173-205 reads beam shapes from it) -- equal stepping in chunks
+    of k and unpacking, bit for bit."""
+    cols = nitinol_columns(n_e, "linear" if n_e < 64 else "nonlinear")
+    B, k, n_rec = 5, 20, 6
+    amps = 0.05 * (1.0 + np.arange(B))
+    ens = ensemble(cols, B, kw)
+    t, snaps = ens.step(k * n_rec + 7, 2e-5, impulse_amp=amps, record="all", record_every=k)
+    assert snaps.shape == (n_rec, B, 2, ens.n_node, 4)
+    red = ens.unpack_snapshots(snaps)
+    assert float(snaps[..., 3].abs().max()) == 0.0
+    ref = ensemble(cols, B, kw)
+    for i in range(n_rec):
+        ref.step(k, 2e-5, impulse_amp=amps)
+        assert torch.equal(red[i], ref.unpack_state()), i
+    ref.step(7, 2e-5, impulse_amp=amps)
+    assert torch.equal(ens.unpack_state(), ref.unpack_state())
