@@ -233,7 +233,8 @@ class BeamEnsemble:
         accepted / rejected steps, nfev, status (0 = reached t_end), next_step.
 
         record=(node, param) with t_eval=(start, step, count): also returns "y" [B, count], that DOF on the
-        uniform grid start + k*step by scipy's dense output (what ``sol.y[i]`` holds when solve_ivp is
+        uniform grid start + k*step by scipy's dense output; record="all": "y" is the whole state on the grid,
+        [count, B, 2, n_node, 4] (unpack_snapshots() gives the reduced ordering) (what ``sol.y[i]`` holds when solve_ivp is
         given ``t_eval=np.arange(...)``, example_utilities.py:158)."""
         if t0 is not None:
             self.time = float(t0)
@@ -259,7 +260,11 @@ class BeamEnsemble:
             h += torch.as_tensor(first_step, dtype=torch.float64, device=self.device)
         stats = torch.zeros((self.n_beams, 4), dtype=torch.int32, device=self.device)
         rec, ys, grid = None, None, (0.0, 0.0, 0)
-        if record is not None:
+        if isinstance(record, str) and record == "all":   # every DOF of sol.y: snapshots [count, B, 2, n_node, 4]
+            grid = (float(t_eval[0]), float(t_eval[1]), int(t_eval[2]))
+            ys = torch.zeros((grid[2],) + tuple(self.state.shape), dtype=self.dtype, device=self.device)
+            rec = nat.RecordDesc(0, -1, 0, 1, ys.data_ptr())
+        elif record is not None:
             node, param = record
             vel = param.startswith("d") and param.endswith("_dt")
             grid = (float(t_eval[0]), float(t_eval[1]), int(t_eval[2]))

@@ -257,17 +257,26 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
                     while (ie < q.n_eval) {
                         const double te = q.eval_t0 + double(ie) * q.eval_dt;
                         if (te > t_new) break;
-                        if (recorder) {
+                        auto dense = [&](int c) {   // scipy RkDenseOutput for component c of this thread's node
                             const double x = (te - tc) / h;
                             double xp = x, acc = 0.0;
-                            const int c = q.eval_comp;
                             for (int m = 0; m < 4; ++m) {
                                 double qm = 0.0;
                                 for (int jj = 0; jj < 7; ++jj) qm += double(Ks[(jj * 6 + c) * NT + t]) * P5[jj][m];
                                 acc += qm * xp;
                                 xp *= x;
                             }
-                            static_cast<T*>(q.eval_out)[size_t(beam) * q.n_eval + ie] = T(h * acc + double(y[c]));
+                            return T(h * acc + double(y[c]));
+                        };
+                        if (q.eval_slot == REC_ALL_SLOTS) {   // whole-state snapshot ie: [n_eval][B][2][n_node][4]
+                            if (valid) {
+                                T* snap = static_cast<T*>(q.eval_out) + size_t(ie) * size_t(p.B) * 2 * plane + xoff;
+                                for (int c = 0; c < 3; ++c) { snap[c] = dense(c); snap[plane + c] = dense(3 + c); }
+                                snap[3] = T(0);
+                                snap[plane + 3] = T(0);
+                            }
+                        } else if (recorder) {
+                            static_cast<T*>(q.eval_out)[size_t(beam) * q.n_eval + ie] = dense(q.eval_comp);
                         }
                         ++ie;
                     }

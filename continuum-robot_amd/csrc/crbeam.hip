@@ -1038,8 +1038,10 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
                                    const crb_input_desc* in, void* h, void* stats, int max_steps,
                                    const crb_record_desc* rec, double eval_t0, double eval_dt, int n_eval, void* stream) {
     if (int rc = need_device(p, "crb_solve_rk45")) return rc;
+    const bool eval_all = rec && rec->node == CRB_RECORD_ALL;
     if (rec && n_eval > 0) {
-        if (rec->plane < 0 || rec->plane > 1 || rec->node < 0 || rec->node >= p->n_node || rec->dof < 0 || rec->dof > 2 ||
+        if ((!eval_all && (rec->plane < 0 || rec->plane > 1 || rec->node < 0 || rec->node >= p->n_node || rec->dof < 0 ||
+                           rec->dof > 2)) ||
             !rec->out || !(eval_dt > 0) || eval_t0 < t0)
             return fail(CRB_EINVAL, "crb_solve_rk45_eval: bad t_eval description");
     }
@@ -1067,7 +1069,9 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
     q.h_io = static_cast<double*>(h); q.stats = static_cast<int32_t*>(stats);
     q.n_state = 2 * p->n_free; q.max_steps = max_steps > 0 ? max_steps : 100000000;
     q.eval_out = nullptr; q.eval_t0 = eval_t0; q.eval_dt = eval_dt; q.n_eval = 0; q.eval_slot = -1; q.eval_comp = 0;
-    if (rec && n_eval > 0 && rec->node - p->off >= 0) {
+    if (rec && n_eval > 0 && eval_all) {
+        q.eval_out = rec->out; q.n_eval = n_eval; q.eval_slot = REC_ALL_SLOTS;
+    } else if (rec && n_eval > 0 && rec->node - p->off >= 0) {
         q.eval_out = rec->out; q.n_eval = n_eval; q.eval_slot = rec->node - p->off; q.eval_comp = rec->plane * 3 + rec->dof;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);

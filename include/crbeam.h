@@ -186,7 +186,8 @@ int crb_solve_rk45(const crb_plan* plan, void* x, double t0, double t_end, doubl
 /* crb_solve_rk45 plus solve_ivp's `t_eval` for one DOF: values on the uniform grid
  * t_eval[k] = eval_t0 + k*eval_dt (k < n_eval, eval_t0 >= t0) by scipy's dense output (RkDenseOutput, the
  * 4th-order interpolant of RK45) -- what the examples read from `sol.y` (example_utilities.py:153-159,
- * 173-205).  rec->every is unused here; rec->out is device [B][n_eval], plan dtype. */
+ * 173-205).  rec->every is unused here; rec->out is device [B][n_eval], plan dtype; with rec->node =
+ * CRB_RECORD_ALL it is [n_eval][B][2][n_node][4] (zero-initialised by the caller): every DOF of sol.y. */
 int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, double rtol, double atol,
                         const crb_input_desc* input, void* h, void* stats, int max_steps,
                         const crb_record_desc* rec, double eval_t0, double eval_dt, int n_eval, void* stream);

@@ -794,3 +794,24 @@ def test_whole_state_snapshots_equal_chunked_stepping(n_e, kw):
         assert torch.equal(red[i], ref.unpack_state()), i
     ref.step(7, 2e-5, impulse_amp=amps)
     assert torch.equal(ens.unpack_state(), ref.unpack_state())
+
+
+def test_adaptive_rk45_dense_output_of_the_whole_state():
+    """solve_rk45(record="all", t_eval=...): every DOF of sol.y on the grid, equal (bit for bit) to the
+    single-DOF dense output of the same integration, for positions and velocities of several nodes."""
+    cols = nitinol_columns(64, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    B = 3
+    amps = 0.05 * (1.0 + np.arange(B))
+    grid = (1e-5, 2.5e-5, 12)
+    ens = ensemble(cols, B, kw)
+    st = ens.solve_rk45(4e-4, rtol=1e-6, atol=1e-9, impulse_amp=amps, t0=0.0, record="all", t_eval=grid)
+    snaps = st["y"]
+    assert snaps.shape == (grid[2], B, 2, ens.n_node, 4)
+    red = ens.unpack_snapshots(snaps)
+    for node, param in ((64, "w"), (64, "dw_dt"), (20, "phi"), (1, "u")):
+        one = ensemble(cols, B, kw)
+        s1 = one.solve_rk45(4e-4, rtol=1e-6, atol=1e-9, impulse_amp=amps, t0=0.0, record=(node, param), t_eval=grid)
+        vel = param.endswith("_dt")
+        idx = one.reduced_index(node, param[1:-3] if vel else param) + (one.n if vel else 0)
+        assert torch.equal(red[:, :, idx].t().contiguous(), torch.as_tensor(s1["y"], device=red.device)), (node, param)
