@@ -815,3 +815,58 @@ def test_adaptive_rk45_dense_output_of_the_whole_state():
         vel = param.endswith("_dt")
         idx = one.reduced_index(node, param[1:-3] if vel else param) + (one.n if vel else 0)
         assert torch.equal(red[:, :, idx].t().contiguous(), torch.as_tensor(s1["y"], device=red.device)), (node, param)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CRB_FUZZ_N", "24"))))   # CRB_FUZZ_N=400 for a long hunt
+def test_randomised_topologies_against_oracle(seed):
+    """Differential test over random beams: size (1..300 elements: several beams per wave, one wave, up to
+    eight waves, padding threads), element kinds, boundary-condition sets (incl. constrained interior nodes and
+    free roots), force sets, held input or impulse, random initial states, per-beam coefficients or shared."""
+    rng = np.random.default_rng(1000 + seed)
+    n_e = int(rng.choice([1, 2, 5, 9, 17, 31, 40, 64, 65, 100, 128, 200, 257, 300]))
+    mode = int(rng.integers(0, 3))
+    kinds = (["linear"] * n_e if mode == 0 else ["nonlinear"] * n_e if mode == 1 else
+             [("nonlinear" if rng.random() < 0.5 else "linear") for _ in range(n_e)])
+    bcs = []
+    for i in range(n_e):
+        r = rng.random()
+        bcs.append("FIXED" if (i == 0 and r < 0.6) or r > 0.995 else ("PINNED" if r > 0.97 else "NONE"))
+    cols = nitinol_columns(n_e, kinds, bcs)
+    kw = {}
+    if rng.random() < 0.5:
+        kw.update(fluid_density=1000.0, enable_fluid=True)
+    if rng.random() < 0.5:
+        kw.update(enable_gravity=True)
+    B = int(rng.integers(1, 7))
+    hetero = rng.random() < 0.3
+    per_beam = [_scaled(cols, rng) for _ in range(B)] if hetero else [cols] * B
+    obs = [oracle_beam(c, **kw) for c in (per_beam if hetero else [cols])]
+    n = obs[0].n
+    ens = ensemble(per_beam if hetero else cols, B, kw)
+    assert ens.n == n
+    x0 = rng.normal(0.0, 1e-5, (B, 2 * n))
+    ens.set_state(x0)
+    steps = int(rng.integers(3, 40))
+    branch = rng.random()
+    if branch < 0.25:     # closed loop: u = K (r - x) at every stage, dense random gain, impulse on top
+        gain = rng.normal(0.0, 1e-2, (n, 2 * n))
+        ref = rng.normal(0.0, 1e-5, (B, 2 * n))
+        amps = rng.uniform(0.01, 0.1, B)
+        idx = int(rng.integers(0, n))
+        ens.step_feedback(steps, 2e-5, gain, reference=ref, impulse_amp=amps, impulse_index=idx, t0=0.0)
+        want = np.array([obs[b if hetero else 0].rk4_feedback(x0[b], 2e-5, steps, gain, reference=ref[b], amp=amps[b], idx=idx)
+                         for b in range(B)])
+    elif branch < 0.6:
+        u = rng.normal(0.0, 1e-3, (B, n))
+        ens.step(steps, 2e-5, held_force=u)
+        want = np.array([obs[b if hetero else 0].rk4_held(x0[b], 2e-5, steps, u[b]) for b in range(B)])
+    else:
+        amps = rng.uniform(0.01, 0.1, B)
+        idx = int(rng.integers(0, n))
+        dur = float(rng.uniform(0.0, steps * 2e-5))
+        ens.step(steps, 2e-5, impulse_amp=amps, impulse_index=idx, impulse_duration=dur, t0=0.0)
+        want = np.array([obs[b if hetero else 0].rk4_impulse(x0[b], 2e-5, steps, amps[b], duration=dur, idx=idx)
+                         for b in range(B)])
+    got = ens.unpack_state().cpu().numpy()
+    assert np.isfinite(want).all()
+    assert rel_err(got, want) < 1e-8, (n_e, mode, bcs[:3], kw, B, hetero)
