@@ -219,9 +219,13 @@ __device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool co
 // over the per-lane branch of EM_MIXED; a wave-uniform run-time branch does not get it).
 // HELD: a per-node input force held over the launch (zero-order-hold control, `u` of dynamic_system(t, x, u)
 // as an array): three more registers and three more additions per stage, so it is its own instantiation.
-template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false>
+// PACK (one-wave form only): beams with fewer than 64 slots, G = 64/S of them per wave (lane = g*S + j).  All
+// exchanges stay DPP lane shifts; what a shift drags across a beam boundary is cancelled by 0/1 masks on the
+// three terms where no zero multiplier does it already (q of the left node, f_left of the right neighbours).
+template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false, bool PACK = false>
 // fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: 3 waves/SIMD (168 VGPRs; 4 waves/SIMD spills)
 __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_step_lean_kernel(const KParams<T> p) {
+    static_assert(!PACK || LOGNW == 0, "packed beams live inside one wave");
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N, RV = LeanRec<T>::V;
     constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
@@ -235,9 +239,12 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int S = p.S;
-    const int j = (lane << LOGNW) | wave;
-    const int beam = blockIdx.x;
-    const bool valid = j < S;
+    const int pg = PACK ? lane / S : 0;                         // beam of this lane inside the wave
+    const int j = PACK ? lane - pg * S : ((lane << LOGNW) | wave);
+    const int beam = PACK ? int(blockIdx.x) * p.G + pg : int(blockIdx.x);
+    const bool valid = PACK ? (pg < p.G && beam < p.B) : (j < S);
+    // 0/1 factors for what a lane shift drags in from the neighbouring beam of a packed wave
+    const T mL = (valid && j >= 1) ? T(1) : T(0), mR1 = (valid && j + 1 < S) ? T(1) : T(0), mR2 = (valid && j + 2 < S) ? T(1) : T(0);
     auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
     // LDS positions of the stride-1 / stride-2 neighbours (NULLT outside the beam)
     const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
@@ -320,7 +327,10 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     T qL[3];
     if (LOGNW == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(xq[c], lane);  // lane 0 reads 0 = clamped / absent root
+        for (int c = 0; c < 3; ++c) {
+            qL[c] = lane_lower<T, 1>(xq[c], lane);  // lane 0 reads 0 = clamped / absent root
+            if (PACK) qL[c] *= mL;
+        }
         if (GRAV) phiR = lane_higher<T, 1>(xq[2], lane);
     } else {
 #pragma unroll
@@ -373,6 +383,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 if (LOGNW == 0) {  // segment j-1 IS the left lane's own segment: take its result (bit-identical), one sincos less
                     g_left[0] = lane_lower<T, 1>(g_own[0], lane);
                     g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+                    if (PACK) { g_left[0] *= mL; g_left[1] *= mL; }
                 } else {
                     gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
                 }
@@ -391,8 +402,14 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                     if (GRAV && c == 2) phiR = lane_higher<T, 1>(qn[2], lane);
                     qL[c] = lane_lower<T, 1>(qn[c], lane);
                     rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
-                    r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
-                    rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+                    if (PACK) {
+                        qL[c] *= mL;
+                        r[c] = pp[c] - mR1 * lane_higher<T, 1>(fl[c], lane);
+                        rhi[c] = lane_higher<T, 1>(pp[c], lane) - mR2 * lane_higher<T, 2>(fl[c], lane);
+                    } else {
+                        r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+                        rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+                    }
                 }
             } else {
                 T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT + 1) * RN : 0);

@@ -9,16 +9,16 @@ namespace crb {
 namespace {
 typedef CRB_LEAN_T T;
 
-template <int LV, int LOGNW, bool GRAV, int EM, bool HELD>
+template <int LV, int LOGNW, bool GRAV, int EM, bool HELD, bool PACK = false>
 hipError_t one_held(const KParams<T>& k, int n_beams, hipStream_t st) {
-    const dim3 grid(n_beams), block(64 << LOGNW);
+    const dim3 grid(PACK ? (n_beams + k.G - 1) / k.G : n_beams), block(64 << LOGNW);
     const size_t smem = lean_lds_bytes<T>(64 << LOGNW, LOGNW);
     if (smem > 64 * 1024) {  // dynamic LDS above 64 KiB is opt-in per kernel (the CU has 160 KiB)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD, PACK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD>), grid, block, smem, st, k);
+    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD, PACK>), grid, block, smem, st, k);
     return hipGetLastError();
 }
 template <int LV, int LOGNW, bool GRAV, int EM>
@@ -26,6 +26,8 @@ hipError_t one(const KParams<T>& k, int n_beams, hipStream_t st) {
 #ifdef CRB_FAST_BUILD
     return one_held<LV, LOGNW, GRAV, EM, false>(k, n_beams, st);
 #else
+    if (LOGNW == 0 && k.G > 1)   // several beams per wave
+        return k.u_held ? one_held<LV, 0, GRAV, EM, true, true>(k, n_beams, st) : one_held<LV, 0, GRAV, EM, false, true>(k, n_beams, st);
     return k.u_held ? one_held<LV, LOGNW, GRAV, EM, true>(k, n_beams, st) : one_held<LV, LOGNW, GRAV, EM, false>(k, n_beams, st);
 #endif
 }

@@ -684,7 +684,9 @@ int launch_beam(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 inline bool lean_eligible(const crb_plan* p, const void* held) {
     const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
     (void)held;   // (a held input has its own instantiation of the lean stepper)
-    return (!grav || p->canonical_gravity) && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
+    // (G > 1: beams of fewer than 64 slots packed into one wave, the PACK instantiation of the one-wave stepper)
+    const bool packed = p->G > 1 && p->lognw == 0 && p->NT == 64 && std::getenv("CRB_DISABLE_LEAN_PACK") == nullptr;
+    return (!grav || p->canonical_gravity) && (p->G == 1 || packed) && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
            p->levels >= 3 && p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr;
 }
 template <typename T>
@@ -701,7 +703,7 @@ int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
 // except that a per-node input force is part of the stage contract.  Shared-table plans run a bounded
 // number of workgroups, each walking over several beams with the solve tables in registers.
 inline bool stage_lean_eligible(const crb_plan* p) {
-    return lean_eligible(p, nullptr) && std::getenv("CRB_DISABLE_LEAN_STAGE") == nullptr;
+    return lean_eligible(p, nullptr) && p->G == 1 && std::getenv("CRB_DISABLE_LEAN_STAGE") == nullptr;
 }
 template <typename T>
 int launch_stage_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
