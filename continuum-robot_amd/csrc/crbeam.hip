@@ -1012,7 +1012,7 @@ int launch_rk45(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hip
     return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: rk45 not built");
 #else
     // plans without gravity, one beam per workgroup of <= 4 waves: the lean RHS (crb_lean.hip)
-    if (!(p->flags & CRB_FORCE_GRAVITY) && p->G == 1 && p->NT == (64 << p->lognw) && p->lognw <= 2 && p->levels >= 3 &&
+    if (!(p->flags & CRB_FORCE_GRAVITY) && p->NT == (64 << p->lognw) && p->lognw <= 2 && p->levels >= 3 &&
         p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr) {
         HIP_TRY(crb::launch_rk45_lean(k, q, p->B, p->levels, p->lognw, p->elem_mode, st));
         return CRB_OK;
@@ -1050,7 +1050,7 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
     if (!x) return fail(CRB_EINVAL, "crb_solve_rk45: null state");
     if (!(t_end > t0)) return fail(CRB_EINVAL, "crb_solve_rk45: t_end must be greater than t0");
     if (!(rtol > 0) || !(atol >= 0)) return fail(CRB_EINVAL, "crb_solve_rk45: tolerances must be positive");
-    if (p->G != 1) return fail(CRB_EUNSUPPORTED, "crb_solve_rk45: beams with fewer than 33 thread-carried nodes are not supported");
+    // (beams of fewer than 64 slots run one per wave here, not packed: every beam has its own step sequence)
     if (rk45_lds_bytes<double>(p->NT) > 160 * 1024)
         return fail(CRB_EUNSUPPORTED, "crb_solve_rk45: beam too long for the LDS-resident stage storage");
     int imp_slot = -1, imp_dof = 0;
