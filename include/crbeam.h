@@ -178,8 +178,8 @@ int crb_step_rk4(const crb_plan* plan, void* x, double t0, double dt, int n_step
  * tests hand their RHS to (tests/test_dynamic_beam.py:218-220, test_functional_composition.py:539-546).
  *   h    device [B] fp64: in  first step per beam (<= 0: scipy's select_initial_step), out next step
  *   stats device [B][4] int32: accepted steps, rejected steps, RHS evaluations, status (0 ok / 1 step
- *        too small or max_steps exceeded).  h and stats may be NULL.  Plans with one beam per workgroup
- *        (n_slots >= 33) only. */
+ *        too small or max_steps exceeded).  h and stats may be NULL.  One beam per workgroup (small beams are
+ *        not packed here: every beam has its own step sequence); beams of up to 256 slots (LDS-resident stages). */
 int crb_solve_rk45(const crb_plan* plan, void* x, double t0, double t_end, double rtol, double atol,
                    const crb_input_desc* input, void* h, void* stats, int max_steps, void* stream);
 
