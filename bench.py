@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- beam-element-steps/s of the fused RK4 beam stepper on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config configX] [--scaling weak|strong]
 
 One "step" = one classical RK4 time step (dt = 2e-5 s) of the whole batch.  Workload at N = 1 is
 BASELINE.json's metric configuration (configs[2]): 4096 beams x 256 nonlinear Euler-Bernoulli
 elements + fluid drag (Nitinol constants of examples/example_utilities.py:25-34, FIXED at node 0,
-zero initial state, per-beam tip impulse 0.1*(1 + b/B) N for t < 0.01 s), fp64.  With N > 1 every
-rank owns 4096 beams of the 4096*N ensemble (independent units, weak scaling, no per-step
-communication) and the terminal states are all-gathered over RCCL inside the timed region.
+zero initial state, per-beam tip impulse 0.1*(1 + b/B) N for t < 0.01 s), fp64.
+
+N > 1: one process per GPU over RCCL.  Started by a launcher (python -m torch.distributed.run ...:
+RANK/LOCAL_RANK/WORLD_SIZE in the environment) this file is rank RANK of WORLD_SIZE; started plainly as
+`python bench.py --gpus N` it IS the launcher: the parent spawns N children of itself before anything touches
+a GPU (no re-exec of a process that has initialised HIP), passes rank 0's JSON line through and exits with the
+first non-zero child status.  Beams are independent units: contiguous shards, no per-step communication, one
+all-gather of the terminal states inside the timed region.  `--scaling weak` keeps the per-GPU ensemble fixed
+(config3: 4096 beams per GPU), `--scaling strong` keeps BASELINE's totals (config3/4: 4096 beams, config5: 16384
+beams) and shards them, raggedly if need be.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit, ms_per_step,
-`roofline` (algorithmic HBM bytes = 96 B per element-step) and `cpu_baseline`
-(the C oracle -- a port of the reference path -- on this box's host cores, bounded sample).
+`roofline` (algorithmic HBM bytes = 96 B per element-step; config5: fp64 MFMA flop of the
+feedback GEMM) and `cpu_baseline` (the C oracle -- a port of the reference path -- on this box's host cores,
+all cores and one core, bounded samples).  The timed region is K steps bracketed by barrier + synchronize; when
+that region is shorter than 50 ms it is repeated (state reset untimed in between) and the MEDIAN is reported.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,33 +35,108 @@ for _p in (ROOT, os.path.join(ROOT, "continuum-robot_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F64_PEAK_TF = 78.6        # MI355X fp64 matrix peak (public spec; measured issue rate 65-71 TF)
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 VALU_CLOCK_HZ = 2.4e9          # nominal engine clock (the chip holds ~2.2 GHz under this fp64 load)
-BYTES_PER_ELEM_STEP = {torch.float64: 96.0, torch.float32: 48.0}
+BYTES_PER_ELEM_STEP = {"f64": 96.0, "f32": 48.0}
+MIN_TIMED_S = 0.05             # shorter timed regions are repeated and the median reported
 
 CONFIGS = {
-    # name: (beams per GPU, elements, element type, force kwargs, random x0, default steps)
-    "config3": dict(beams=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False,
+    # name: beams per GPU (weak) / total (strong), elements, element type, forces, random x0, defaults
+    "config3": dict(beams=4096, total=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False,
+                    scaling="weak",
                     label="4096 beams x 256 elem, nonlinear Euler-Bernoulli + fluid drag, fp64"),
-    # BASELINE config 4: the same ensemble in fp32 (batch-sharded across the node's GPUs); 200 steps by default,
-    # beyond which single precision drifts past 1e-5 from the fp64 oracle
-    "config4": dict(beams=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False, dtype="f32", steps=200,
+    # BASELINE config 4: the same ensemble in fp32, batch-sharded across the node's GPUs (fixed total); 200 steps by
+    # default, beyond which single precision drifts past 1e-5 from the fp64 oracle
+    "config4": dict(beams=4096, total=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False, dtype="f32",
+                    steps=200, scaling="strong",
                     label="4096 beams x 256 elem, nonlinear Euler-Bernoulli + fluid drag, fp32"),
-    "config2": dict(beams=1024, elems=64, kind="linear", drag=False, gravity=True, x0=True,
+    "config2": dict(beams=1024, total=1024, elems=64, kind="linear", drag=False, gravity=True, x0=True, scaling="weak",
                     label="1024 beams x 64 elem, linear + gravity, fp64"),
-    # LQR rollout ensemble (BASELINE config 5: 2048 beams/GPU): state feedback u = K(0 - x) at every RK4
-    # stage (stage-split path: one GEMM + one stage kernel per stage).  dt = 5e-6: the closed loop has
+    # LQR rollout ensemble (BASELINE config 5: 16384 beams, 2048 per GPU on 8 GPUs): state feedback u = K(0 - x) at
+    # every RK4 stage (stage-split path: one GEMM + one stage kernel per stage).  dt = 5e-6: the closed loop has
     # |lambda|max = 3.2e5 1/s, RK4 is unstable at the open-loop dt = 2e-5.
-    "config5": dict(beams=2048, elems=128, kind="linear", drag=False, gravity=True, x0=True, lqr=True, dt=5e-6,
-                    amp=10.0, label="2048 beams/GPU x 128 elem, linear + gravity + LQR feedback per stage, fp64"),
+    "config5": dict(beams=2048, total=16384, elems=128, kind="linear", drag=False, gravity=True, x0=True, lqr=True,
+                    dt=5e-6, amp=10.0, scaling="weak",
+                    label="LQR rollout ensemble x 128 elem, linear + gravity + LQR feedback per stage, fp64"),
 }
 
 
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed RK4 steps (default 1000; 200 for config4)")
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"], help="default: the config's (f64; config4: f32)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: the config's beams on EVERY GPU; strong: BASELINE's total (config3/4 4096, config5 16384) "
+                         "sharded over the GPUs.  Default: the config's (config4: strong, the others weak)")
+    ap.add_argument("--launch-steps", type=int, default=100,
+                    help="RK4 steps fused per launch (0 = all of --steps); warmup uses launches of the same size, so "
+                         "every stepper launch of a run is identical and rocprof's per-kernel average is the launch time")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed repeats of the K-step rollout (0 = as many as a 50 ms timed region needs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-all", action="store_true",
+                    help="after timing, compare EVERY beam of rank 0 with the oracle (open-loop configs; tens of CPU-seconds)")
+    ap.add_argument("--hetero", action="store_true",
+                    help="heterogeneous variant (SURVEY 8(d)): per-beam E, rho, r scaled by U(0.9, 1.1), seed 4321")
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config]
+    if args.dtype is None:
+        args.dtype = cfg.get("dtype", "f64")
+    if args.steps is None:
+        args.steps = cfg.get("steps", 1000)
+    if args.scaling is None:
+        args.scaling = cfg["scaling"]
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
+    return args
+
+
+# ------------------------------------------------------------------ launcher (parent process: never touches a GPU)
+def launch(n_ranks, argv):
+    """Start ``n_ranks`` children of this script, one per GPU, with the torch.distributed environment; rank 0's
+    stdout (the JSON line) is this process's stdout, the other ranks' stdout goes to stderr.  Returns the exit
+    status: 0, or the first non-zero child status (the remaining children are then terminated by PID)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    worker = os.environ.get("CRB_BENCH_WORKER") or os.path.abspath(__file__)   # (tests substitute a stub worker)
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CRB_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, worker] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    live = set(range(n_ranks))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and status == 0:
+                status = rc
+                print(f"[bench launcher] rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return status
+
+
+# ------------------------------------------------------------------ host-side pieces
 def lqr_gain(ens):
     """LQR gain of lqr_control.py:46-84 for the ensemble's (linear) beam: Q = diag(100 I, 10 I), R = I."""
+    import numpy as np
+
     from continuum_robot.control import LinearQuadraticRegulator
 
     K, M = ens.plan.stiffness(), ens.plan.mass()
@@ -62,60 +147,64 @@ def lqr_gain(ens):
     return LinearQuadraticRegulator(K, M, Q, np.eye(n)).compute_gain_matrix()
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed RK4 steps (default 1000; 200 for config4)")
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="config3", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default=None, choices=["f64", "f32"], help="default: the config's (f64; config4: f32)")
-    ap.add_argument("--launch-steps", type=int, default=100,
-                    help="RK4 steps fused per launch (0 = all of --steps); warmup uses launches of the same size, so "
-                         "every stepper launch of a run is identical and rocprof's per-kernel average is the launch time")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify-all", action="store_true",
-                    help="after timing, compare EVERY beam of rank 0 with the oracle (open-loop configs; tens of CPU-seconds)")
-    ap.add_argument("--hetero", action="store_true",
-                    help="heterogeneous variant (SURVEY 8(d)): per-beam E, rho, r scaled by U(0.9, 1.1), seed 4321")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    if args.dtype is None:
-        args.dtype = cfg.get("dtype", "f64")
-    if args.steps is None:
-        args.steps = cfg.get("steps", 1000)
-    return args
+def initial_states(lo, hi, n):
+    """SURVEY §8(d) random initial states of the linear configs, generated per 512-beam block of the GLOBAL
+    ensemble so that beam b starts from the same state whatever the number of ranks."""
+    import numpy as np
+
+    rows = []
+    for blk in range(lo // 512, (hi - 1) // 512 + 1):
+        rng = np.random.default_rng([1234, blk])
+        x = np.concatenate([rng.normal(0, 1e-5, (512, n)), rng.normal(0, 1e-3, (512, n))], axis=1)
+        a, b = max(lo, blk * 512) - blk * 512, min(hi, (blk + 1) * 512) - blk * 512
+        rows.append(x[a:b])
+    x0 = np.concatenate(rows, axis=0)
+    x0[:, 0:n:3] = 0.0
+    x0[:, n::3] = 0.0
+    return x0
 
 
-def cpu_baseline(cols, kw, n_elem, target_s=15.0):
-    """Time the C oracle (port of the reference path) on this box's host cores, bounded sample."""
+def cpu_baseline(cols, kw, n_elem, target_s=10.0):
+    """Time the C oracle (port of the reference path) on this box's host cores: all cores the process may use, and
+    ONE core (SURVEY §8(d) asks for both), bounded samples of the same workload."""
+    import numpy as np
+
     from tests.helpers import oracle_beam
 
     ob = oracle_beam(cols, **kw)
-    # host cores this process may use (a 1-GPU box's share is 16 of the host's cores)
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))   # a 1-GPU box's share is 16 of the host's cores
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("CRB_BENCH_CPU_THREADS", "16"))))
-    # calibrate on one beam, then size the sample for ~target_s of wall time on all cores
+    cores = max(1, min(cores, int(os.environ.get("CRB_BENCH_CPU_THREADS", "64"))))
     t0 = time.perf_counter()
     ob.rk4_impulse(np.zeros(2 * ob.n), 2e-5, 20, 0.1)
     per_beam_step = (time.perf_counter() - t0) / 20
     steps = 200
-    beams = int(max(cores, min(4096, target_s * cores / (per_beam_step * steps))))
-    beams = (beams // cores) * cores or cores
-    amps = 0.1 * (1.0 + np.arange(beams) / beams)
-    t0 = time.perf_counter()
-    _, used = ob.rk4_impulse_batch(np.zeros((beams, 2 * ob.n)), 2e-5, steps, amps, n_threads=cores)
-    wall = time.perf_counter() - t0
-    return {"value": beams * n_elem * steps / wall, "unit": "beam-element-steps/s", "cores": int(used), "kind": "port",
-            "sample": f"{beams} beams x {n_elem} elem x {steps} RK4 steps, C oracle (oracle/crb_oracle.c), "
-                      f"OpenMP over beams, {wall:.1f} s wall",
-            "reference_python_1core": 3796.0}  # BASELINE.md §2, measured in the survey container
+
+    def sample(threads, budget_s):
+        beams = int(max(threads, min(4096, budget_s * threads / (per_beam_step * steps))))
+        beams = (beams // threads) * threads or threads
+        amps = 0.1 * (1.0 + np.arange(beams) / beams)
+        t0 = time.perf_counter()
+        _, used = ob.rk4_impulse_batch(np.zeros((beams, 2 * ob.n)), 2e-5, steps, amps, n_threads=threads)
+        wall = time.perf_counter() - t0
+        return {"value": beams * n_elem * steps / wall, "unit": "beam-element-steps/s", "cores": int(used),
+                "sample": f"{beams} beams x {n_elem} elem x {steps} RK4 steps, C oracle (oracle/crb_oracle.c), "
+                          f"{'OpenMP over beams' if threads > 1 else 'one thread'}, {wall:.1f} s wall"}
+
+    out = sample(cores, target_s)
+    out["kind"] = "port"
+    out["host_cpu_count"] = os.cpu_count()
+    out["one_core"] = sample(1, 0.6 * target_s)
+    out["reference_python_1core"] = 3796.0   # BASELINE.md §2, measured in the survey container (reference proper)
+    return out
 
 
-def main():
-    args = parse()
+def worker(args):
+    import numpy as np
+    import torch
+
     # stdout carries exactly ONE line (the JSON result): libraries that chat on fd 1 (RCCL prints its
     # version banner there) are redirected to stderr for the duration of the run
     sys.stdout.flush()
@@ -125,7 +214,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the stepper has no CPU path")
@@ -139,14 +228,22 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    import ctypes as C
+
+    from continuum_robot import _native as nat
     from continuum_robot.batched import BeamEnsemble
-    from continuum_robot.distributed import gather_terminal_states, impulse_amplitudes, shard_range
+    from continuum_robot.distributed import gather_terminal_states, impulse_amplitudes, shard_range, shard_sizes
     from continuum_robot.models.force_params import ForceParams
-    from tests.helpers import nitinol_columns, oracle_beam, rel_err
+    from tests.helpers import block_errs, nitinol_columns, oracle_beam, rel_err, rollout_conditioning
 
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
-    B, ne = cfg["beams"], cfg["elems"]
-    B_total = B * world
+    ne = cfg["elems"]
+    B_total = cfg["beams"] * world if args.scaling == "weak" else cfg["total"]
+    lo, hi = shard_range(B_total, world, rank)
+    B = hi - lo
+    sizes = shard_sizes(B_total, world)
+    if B < 1:
+        raise SystemExit(f"rank {rank} owns no beam of {B_total}")
     cols = nitinol_columns(ne, cfg["kind"])
     fp = ForceParams(fluid_density=1000.0 if cfg["drag"] else 0.0, enable_fluid_effects=cfg["drag"],
                      enable_gravity_effects=cfg["gravity"])
@@ -169,21 +266,15 @@ def main():
     torch.cuda.synchronize()
     plan_ms = (time.perf_counter() - t_plan) * 1e3
 
-    lo, hi = shard_range(B_total, world, rank)
-    assert hi - lo == B
     amps = torch.as_tensor(impulse_amplitudes(B_total, lo, hi, cfg.get("amp", 0.1)), dtype=dtype, device=ens.device)
     gain = None
     if cfg.get("lqr"):
         t_gain = time.perf_counter()
         gain = torch.as_tensor(lqr_gain(ens), dtype=dtype, device=ens.device)
         print(f"[bench] LQR gain {tuple(gain.shape)} solved in {time.perf_counter() - t_gain:.1f} s", file=sys.stderr)
-    x0 = None
+    x0 = x0n = None
     if cfg["x0"]:
-        rng = np.random.default_rng(1234 + rank)
-        n = ens.n
-        x0n = np.concatenate([rng.normal(0, 1e-5, (B, n)), rng.normal(0, 1e-3, (B, n))], axis=1)
-        x0n[:, 0:n:3] = 0.0
-        x0n[:, n::3] = 0.0
+        x0n = initial_states(lo, hi, ens.n)
         x0 = ens.pack_state(x0n)
 
     def reset():
@@ -195,6 +286,7 @@ def main():
 
     dt = cfg.get("dt", 2e-5)
     per_launch = args.launch_steps if args.launch_steps > 0 else args.steps
+    per_launch = min(per_launch, args.steps)
 
     def advance(k):
         if gain is None:
@@ -221,44 +313,57 @@ def main():
     if dist:
         # warm the collective path too (RCCL builds its communicator / channels lazily on first use:
         # tens of ms that do not belong to the timed steps)
-        gather_terminal_states(ens.unpack_state())
+        gather_terminal_states(ens.unpack_state(), sizes=sizes)
         warm = torch.zeros(1, dtype=torch.float64, device=ens.device)
         dist.all_reduce(warm, op=dist.ReduceOp.MAX)
         dist.barrier()
-    reset()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
 
     events = []
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    done = 0
-    while done < args.steps:
-        k = min(per_launch, args.steps - done)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        advance(k)
-        e1.record()
-        events.append((e0, e1, k))
-        done += k
-    # the one exchange: RCCL all-gather of the terminal states in the reference's reduced ordering
-    # ([B, 2n], no padding lanes: 50 MB per rank for config 3); no-op at N = 1
-    gathered = gather_terminal_states(ens.unpack_state())
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    wall = time.perf_counter() - t_start
-    if dist:
-        tmax = torch.tensor([wall], dtype=torch.float64, device=ens.device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+
+    def timed_rollout():
+        """EXACTLY --steps steps bracketed by barrier + synchronize on both sides; returns (max-over-ranks wall, gathered)."""
+        reset()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        done = 0
+        while done < args.steps:
+            k = min(per_launch, args.steps - done)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()   # (the stepper launches on torch's current stream: BeamEnsemble._stream)
+            advance(k)
+            e1.record()
+            events.append((e0, e1, k))
+            done += k
+        # the one exchange: RCCL all-gather of the terminal states in the reference's reduced ordering
+        # ([B, 2n], no padding lanes: 50 MB per rank for config 3); no-op at N = 1
+        gathered = gather_terminal_states(ens.unpack_state(), sizes=sizes)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        wall = time.perf_counter() - t_start
+        if dist:
+            tmax = torch.tensor([wall], dtype=torch.float64, device=ens.device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        return wall, gathered
+
+    walls = []
+    wall, gathered = timed_rollout()
+    walls.append(wall)
+    # a region shorter than 50 ms is not a measurement to rank kernels by: repeat it (every rank derives the same
+    # count from the max-reduced first wall) and report the median
+    repeats = args.repeats if args.repeats > 0 else max(1, min(1000, int(np.ceil(MIN_TIMED_S / max(wall, 1e-6)))))
+    for _ in range(repeats - 1):
+        wall, gathered = timed_rollout()
+        walls.append(wall)
+    wall = float(np.median(walls))
 
     kernel_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
     full = [ms for (ms, (_, _, k)) in zip(kernel_ms, events) if k == per_launch] or kernel_ms
     avg_launch_s = float(np.mean(full)) * 1e-3
-    algo_bytes_launch = BYTES_PER_ELEM_STEP[dtype] * B * ne * min(per_launch, args.steps)
-    achieved = algo_bytes_launch / avg_launch_s / 1e9
 
     # ---- sanity / parity of what was just timed (after the clock stopped)
     state = ens.unpack_state()
@@ -271,8 +376,15 @@ def main():
         if gain is None:
             ref = ob.rk4_impulse(x0b, dt, args.steps, float(amps[b].item()))
         else:
-            ref = ob.rk4_feedback(x0b, dt, args.steps, gain.cpu().numpy(), amp=float(amps[b].item()))
-        check["rel_err_vs_oracle_last_beam"] = rel_err(state[b].double().cpu().numpy(), ref)
+            ref = ob.rk4_feedback(x0b, dt, args.steps, gain.double().cpu().numpy(), amp=float(amps[b].item()))
+        got_b = state[b].double().cpu().numpy()
+        check["rel_err_vs_oracle_last_beam"] = rel_err(got_b, ref)
+        # per DOF block (u, w, phi and their rates), each relative to its own largest entry (tests/helpers.block_errs)
+        check["block_err_vs_oracle_last_beam"] = block_errs(got_b, ref, ens.free_index)
+        if gain is None and cfg["kind"] == "nonlinear" and args.dtype == "f64":
+            # how ill-conditioned the trajectory itself is: the oracle's own per-block response to a 4-ulp change of the
+            # impulse amplitude (the axial blocks of long nonlinear chains are exponentially unstable beyond ~600 steps)
+            check["oracle_block_sensitivity_4ulp"] = rollout_conditioning(ob, x0b, dt, args.steps, float(amps[b].item()))
         check["tip_w_last_beam"] = float(state[b, ens.n - 2].item())
         if args.verify_all and gain is None and not args.hetero:
             X0 = np.zeros((B, 2 * ob.n)) if x0 is None else x0n
@@ -280,7 +392,59 @@ def main():
             got_all = state.double().cpu().numpy()
             errs = np.linalg.norm(got_all - ref_all, axis=1) / np.maximum(np.linalg.norm(ref_all, axis=1), 1e-300)
             check["rel_err_vs_oracle_all_beams_max"] = float(errs.max())
+            check["block_err_vs_oracle_all_beams_max"] = block_errs(got_all, ref_all, ens.free_index)
             check["beams_compared"] = int(B)
+
+    # ---- roofline of the dominant kernel
+    if gain is None:
+        algo_bytes_launch = BYTES_PER_ELEM_STEP[args.dtype] * B * ne * per_launch
+        achieved = algo_bytes_launch / avg_launch_s / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "crb_step_lean_kernel",
+                    "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_launch,
+                    "valu_issue_frac": None}
+    else:
+        # config 5: the dominant kernel is the feedback GEMM U = (R - X) K^T on the fp64 matrix cores;
+        # both kernels of a stage are timed on their own here, live, with HIP events on the launch stream
+        lib = nat.load()
+        vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        u = torch.zeros((B, ens.n_node, 4), dtype=dtype, device=ens.device)
+        acc, nxt = torch.empty_like(ens.state), torch.empty_like(ens.state)
+        stream = C.c_void_p(torch.cuda.current_stream(ens.device).cuda_stream)
+        reps = 50
+
+        def time_kernel(fn):
+            for _ in range(5):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        gemm_s = time_kernel(lambda: nat.check(lib.crb_feedback_force(ens.plan.h, vp(ens.state), vp(gain), None, vp(u), stream)))
+        stage_s = time_kernel(lambda: nat.check(lib.crb_rk4_stage(ens.plan.h, vp(ens.state), vp(ens.state), vp(acc), vp(nxt),
+                                                                  vp(u), 1, 0.0, dt, None, stream)))
+        n = ens.n
+        gemm_flop = 2.0 * B * (2 * n) * n
+        peak_tf = MFMA_F64_PEAK_TF if args.dtype == "f64" else MFMA_F32_PEAK_TF
+        ach_tf = gemm_flop / gemm_s / 1e12
+        itemsize = 8 if args.dtype == "f64" else 4
+        stage_bytes = 12 * 4 * itemsize * B * ne     # 8 record reads + 4 record writes of 4 values per node-stage
+        step_s = avg_launch_s / per_launch
+        roofline = {"bound": "mfma_f64" if args.dtype == "f64" else "mfma_f32", "achieved": ach_tf, "peak": peak_tf,
+                    "unit": "TFLOP/s", "frac": ach_tf / peak_tf, "traffic": None,
+                    "kernel": "crb_feedback_ws_kernel", "avg_launch_ms": gemm_s * 1e3,
+                    "algorithmic_flop_per_launch": gemm_flop,
+                    "whole_step": {"flop": 4 * gemm_flop, "ms": step_s * 1e3, "achieved": 4 * gemm_flop / step_s / 1e12,
+                                   "frac": 4 * gemm_flop / step_s / 1e12 / peak_tf,
+                                   "launches_per_step": 8},
+                    "stage_kernel": {"kernel": "crb_stage_lean_kernel", "bound": "hbm", "avg_launch_ms": stage_s * 1e3,
+                                     "algorithmic_bytes_per_launch": stage_bytes,
+                                     "achieved": stage_bytes / stage_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": stage_bytes / stage_s / 1e9 / HBM_PEAK_GBS}}
 
     if rank == 0:
         value = B_total * ne * args.steps / wall
@@ -293,39 +457,43 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": cfg["label"] + (" [heterogeneous: per-beam coefficients]" if args.hetero else ""), "beams_per_gpu": B, "beams_total": B_total, "elements": ne,
-                       "dt": dt, "steps_per_launch": min(per_launch, args.steps), "parallelism": f"beam-shard x{world}",
-                       "collective": "all_gather_into_tensor(terminal states [B,2n])" if world > 1 else "none",
+            "repeats": repeats,
+            "timed_region_ms": {"median": wall * 1e3, "min": min(walls) * 1e3, "max": max(walls) * 1e3,
+                                "total": sum(walls) * 1e3},
+            "config": {"workload": cfg["label"] + (" [heterogeneous: per-beam coefficients]" if args.hetero else ""),
+                       "beams_per_gpu": sizes, "beams_total": B_total, "elements": ne,
+                       "dt": dt, "steps_per_launch": per_launch, "parallelism": f"beam-shard x{world}",
+                       "ranks_seen": int(dist.get_world_size()) if dist else 1,
+                       "launched_by": "bench.py launcher" if os.environ.get("CRB_BENCH_LAUNCHED") else
+                                      ("external launcher" if "WORLD_SIZE" in os.environ else "single process"),
+                       "collective": ("all_gather_into_tensor(terminal states [B,2n]" +
+                                      (", padded to the largest shard)" if min(sizes) != max(sizes) else ")")) if dist else "none",
                        "plan_ms": plan_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": ("crb_stage_lean_kernel + crb_feedback_kernel" if gain is not None
-                                    else "crb_step_lean_kernel"),
-                         "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "valu_issue_frac": None},
+            "roofline": roofline,
             "check": check,
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and world == 1:
             try:
                 tj = json.load(open(traffic_file))
-                key = f"{args.config}:{args.dtype}:{min(per_launch, args.steps)}"
+                # HBM traffic of a stepper launch is one read + one write of the state, whatever the number of fused
+                # steps: keyed by config and dtype only (PMC passes of profiles/pmc_traffic.sh)
+                key = f"{args.config}:{args.dtype}" + (":hetero" if args.hetero else "")
                 if key in tj:
                     out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tj[key].get("source")
-                    if "valu_instr_per_elem_step" in tj[key]:
+                    if "valu_instr_per_elem_step" in tj[key] and gain is None:
                         # the limiter that actually binds: vector-ALU issue slots (one wave instruction per
                         # SIMD every 4 cycles, 1024 SIMDs, nominal 2.4 GHz), instruction count from the PMC run
-                        lane_instr = tj[key]["valu_instr_per_elem_step"] * B * ne * min(per_launch, args.steps) / avg_launch_s
+                        lane_instr = tj[key]["valu_instr_per_elem_step"] * B * ne * per_launch / avg_launch_s
                         out["roofline"]["valu_issue_frac"] = lane_instr / (1024 * 64 * VALU_CLOCK_HZ / 4)
                         out["roofline"]["valu_source"] = tj[key].get("valu_source")
-            except Exception:
-                pass
+            except Exception as e:  # a malformed side file must not cost the run its result line
+                print(f"[bench] profiles/traffic.json ignored: {e}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cols, okw, ne)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -333,5 +501,15 @@ def main():
         dist.destroy_process_group()
 
 
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("CRB_BENCH_FORCE_DIST") == "1"):
+        # plain `python bench.py --gpus N`: this process is the launcher.  Nothing above imported torch or touched HIP.
+        return launch(args.gpus, argv)
+    worker(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -68,10 +68,11 @@ class BeamEnsemble:
             self.columns = [_columns(p, fp.enable_fluid_effects) for p in parameters]
         else:
             self.columns = _columns(parameters, fp.enable_fluid_effects)
-        self.plan = nat.Plan(self.columns, n_beams=n_beams, node_bc=node_bc, fluid_density=fp.fluid_density,
-                             enable_fluid=fp.enable_fluid_effects, gravity=fp.get_gravity_vector(),
-                             enable_gravity=fp.enable_gravity_effects, corrected_axial=corrected_axial,
-                             dtype="f64" if dtype == torch.float64 else "f32", device=self.device.index)
+        with torch.cuda.device(self.device):   # (plan creation selects the plan's device: keep the caller's current one)
+            self.plan = nat.Plan(self.columns, n_beams=n_beams, node_bc=node_bc, fluid_density=fp.fluid_density,
+                                 enable_fluid=fp.enable_fluid_effects, gravity=fp.get_gravity_vector(),
+                                 enable_gravity=fp.enable_gravity_effects, corrected_axial=corrected_axial,
+                                 dtype="f64" if dtype == torch.float64 else "f32", device=self.device.index)
         p = self.plan
         self.n_beams, self.n_elem, self.n_node, self.n = n_beams, p.n_elem, p.n_node, p.n_free
         self.free_index = p.free_index.copy()
@@ -276,10 +277,19 @@ class BeamEnsemble:
                                                     int(max_steps), C.byref(rec) if rec is not None else None, grid[0],
                                                     grid[1], grid[2], self._stream()))
         self._keep = keep + [h, stats, ys]
-        self.time = float(t_end)
         st = stats.cpu().numpy()
         out = {"accepted": st[:, 0], "rejected": st[:, 1], "nfev": st[:, 2], "status": st[:, 3],
                "next_step": h.cpu().numpy()}
+        if np.any(st[:, 3] != 0):
+            # a beam that gave up (step too small / max_steps) stopped BEFORE t_end: the ensemble no longer has one
+            # clock, so the clock is not advanced and the caller is told (scipy reports status -1 the same way)
+            import warnings
+
+            bad = np.nonzero(st[:, 3] != 0)[0]
+            warnings.warn(f"solve_rk45: {bad.size} of {self.n_beams} beams stopped before t_end (first: beam {int(bad[0])}); "
+                          "ensemble clock left unchanged", RuntimeWarning, stacklevel=2)
+        else:
+            self.time = float(t_end)
         if ys is not None:
             out["y"] = ys
         return out

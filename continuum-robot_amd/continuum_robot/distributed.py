@@ -6,7 +6,7 @@ code runs on "gloo" for the CPU tests of the sharding logic.  The reference's on
 multiprocessing.Pool.map over independent simulations (examples/beam_comparison_fluid.py:82-83);
 this is its counterpart.
 """
-from typing import Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -22,22 +22,52 @@ def shard_range(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_sizes(n_total: int, world_size: int) -> List[int]:
+    """Number of beams every rank owns under ``shard_range`` (no communication needed to know it)."""
+    return [hi - lo for lo, hi in (shard_range(n_total, world_size, r) for r in range(world_size))]
+
+
 def impulse_amplitudes(n_total: int, lo: int, hi: int, base_amp: float = 0.1) -> np.ndarray:
     """Per-beam tip-impulse amplitudes of the synthetic ensembles:
     a_b = base_amp * (1 + b / B) with b the GLOBAL beam index."""
     return base_amp * (1.0 + np.arange(lo, hi) / n_total)
 
 
-def gather_terminal_states(local: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather equally sized per-rank tensors along dim 0, in rank order.
+def gather_terminal_states(local: torch.Tensor, group=None, sizes: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """All-gather per-rank tensors along dim 0, in rank order; shards may be RAGGED (``shard_range`` hands out
+    unequal ones whenever the ensemble size is not a multiple of the world size).
 
-    One collective per rollout: with nccl this is a single RCCL all-gather (direct over the xGMI
-    mesh); message = local.numel() * itemsize bytes per rank.
+    ``sizes``: rows owned by every rank when the caller knows them (``shard_sizes``); otherwise they are
+    exchanged first (one tiny all-gather).  Equal shards: one ``all_gather_into_tensor`` (with nccl a single
+    RCCL all-gather, direct over the xGMI mesh; message = local.numel() * itemsize bytes per rank).  Ragged
+    shards: every rank pads its block to the largest shard, the same single collective runs on the padded
+    blocks, and the padding rows are cut out of the result.
     """
     if not dist.is_initialized():
         return local
     world = dist.get_world_size(group)
     local = local.contiguous()
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local, group=group)
-    return out
+    if sizes is None:
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        every = torch.empty((world,), dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        sizes = [int(v) for v in every.cpu().tolist()]
+    else:
+        sizes = [int(v) for v in sizes]
+        if len(sizes) != world:
+            raise ValueError(f"sizes has {len(sizes)} entries for a world of {world}")
+        if sizes[dist.get_rank(group)] != local.shape[0]:
+            raise ValueError(f"rank {dist.get_rank(group)} holds {local.shape[0]} rows, sizes says {sizes[dist.get_rank(group)]}")
+    tail = tuple(local.shape[1:])
+    biggest = max(sizes)
+    if min(sizes) == biggest:
+        out = torch.empty((world * biggest,) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    padded = local
+    if local.shape[0] < biggest:
+        padded = torch.zeros((biggest,) + tail, dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+    out = torch.empty((world * biggest,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * biggest:r * biggest + sizes[r]] for r in range(world)], dim=0)

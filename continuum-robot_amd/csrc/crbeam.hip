@@ -491,11 +491,16 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
             delete p;
             return fail(CRB_ENODEV, "crb_plan_create: HIP device not available (no fallback path exists)");
         }
+        // plan creation works on the plan's device and hands the caller's current device back (launch entry points
+        // select the plan's device and leave it selected, as a HIP stream of that device must be current anyway)
+        int prev = -1;
+        (void)hipGetDevice(&prev);
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete p; return fail(CRB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
         // ======== device plan: crb_assemble_kernel builds every floating-point table ========
         const int rc = (dtype == CRB_F64) ? device_assemble<double>(p, d, nd, slots, free_dof)
                                           : device_assemble<float>(p, d, nd, slots, free_dof);
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
         if (rc != CRB_OK) { crb_plan_destroy(p); return rc; }
     }
     *out = p;

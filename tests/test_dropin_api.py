@@ -14,7 +14,14 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from tests.helpers import COLS, beam_columns, force_kwargs, rel_err
+from tests.helpers import COLS, assert_blocks, beam_columns, force_kwargs, rel_err
+
+
+def _free_index(beam):
+    """reduced -> full DOF index (3 * node + {u, w, phi}) of a drop-in beam, from its public DOF map."""
+    order = {"u": 0, "w": 1, "phi": 2}
+    d = beam.beam_model.dof_to_node_param
+    return np.array([3 * d[r][1] + order[d[r][0]] for r in range(len(d))])
 
 
 def write_csv(cols, drop=()):
@@ -390,11 +397,13 @@ def test_dynamic_system_matches_reference(golden, bname, fname):
     dyn = beam.get_dynamic_system()
     X, U, ref = z[f"{key}/x"], z[f"{key}/u"], z[f"{key}/xdot"]
     n = beam.beam_model.M.shape[0]
+    fi = _free_index(beam)
     for i in range(2):
         for j in (1, 3):
             out = dyn(0.0, X[i], U[j])
-            assert out.shape == (2 * n,) and rel_err(out, ref[i, j]) < 1e-10
-        assert rel_err(dyn(0.3, X[i], lambda t: U[2] * (t < 1.0)), ref[i, 2]) < 1e-10  # callable input
+            assert out.shape == (2 * n,)
+            assert_blocks(out, ref[i, j], fi, 1e-10)   # every DOF block of [v ; a]
+        assert_blocks(dyn(0.3, X[i], lambda t: U[2] * (t < 1.0)), ref[i, 2], fi, 1e-10)  # callable input
     k = beam.beam_model.get_stiffness_function()(X[0][:n])
     assert k.shape == (n,)
     with pytest.raises(ValueError, match="must match position DOFs"):
@@ -493,7 +502,7 @@ def test_to_ensemble_is_the_fused_path(beam_files):
     U = np.random.default_rng(2).normal(0, 1.0, (3, n))
     fused = ens.rhs(X, U).cpu().numpy()
     for b in range(3):  # closure path (host force callables + RHS kernel) == fused kernel path
-        assert rel_err(beam.get_dynamic_system()(0.0, X[b], U[b]), fused[b]) < 1e-12
+        assert_blocks(beam.get_dynamic_system()(0.0, X[b], U[b]), fused[b], ens.free_index, 1e-12)
 
 
 @gpu
@@ -518,7 +527,7 @@ def test_fused_registry_path_equals_host_composed_path_and_follows_runtime_chang
 
     def same():
         a, b = fused.get_system_func()(x), hosted.get_system_func()(x)
-        assert rel_err(a, b) < 1e-12
+        assert_blocks(a, b, _free_index(fused), 1e-12)
         return a
 
     base = same()

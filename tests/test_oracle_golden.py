@@ -8,7 +8,7 @@ differ from the reference only by band-Cholesky-vs-explicit-inverse rounding
 import numpy as np
 import pytest
 
-from tests.helpers import beam_columns, force_kwargs, oracle_beam, rel_err
+from tests.helpers import assert_blocks, beam_columns, force_kwargs, oracle_beam, rel_err, rollout_conditioning
 
 G2_BEAMS = ["test4_lin", "test4_nl", "mixed5", "hetero7"]
 G2_SETS = ["none", "fixed0", "pinned0", "fixed0_pinned2", "pinned0_pinnedN"]
@@ -87,7 +87,9 @@ def test_g3_g4_forces_and_rhs(golden, bname, fname):
     for i, x in enumerate(X):
         for j, u in enumerate(z[f"{key}/u"]):
             got = ob.rhs(x, u)
-            assert rel_err(got, z[f"{key}/xdot"][i, j]) < 1e-10, (i, j)
+            # per DOF block of [v ; a] (bar 1e-6): the band solve and the reference's explicit inverse differ by
+            # cond(M) ~ 1e4 roundings
+            assert_blocks(got, z[f"{key}/xdot"][i, j], ob.red2full(), 1e-10, what=(i, j))
 
 
 G5 = ["lin10_grav", "lin64_grav", "lin64_grav_x0", "nl64_drag", "nl256_drag", "nl256_drag_a2", "mixed5_both",
@@ -109,9 +111,13 @@ def test_g5_rk4_rollouts(golden, name):
             t = t + dt
         done = int(c)
         ref = z[f"{name}/x_{c}"]
-        # 1e-6 is north_star's bar; band-solve-vs-explicit-inverse rounding stays far below it
-        assert rel_err(x, ref) < 1e-8, (name, c, rel_err(x, ref))
-        assert abs(x[ob.n - 2] - ref[ob.n - 2]) <= 1e-9 * abs(ref[ob.n - 2])
+        # 1e-6 per DOF block is north_star's bar; band-solve-vs-explicit-inverse rounding stays far below it
+        # (measured <= 3.3e-12 in every block of every rollout) EXCEPT in the axial blocks of the long nonlinear
+        # chains beyond ~600 steps, which the shipped f1 makes exponentially unstable (helpers.assert_blocks):
+        # there the bound is the oracle's own sensitivity to a 64-ulp change of the impulse amplitude
+        cond = rollout_conditioning(ob, z[f"{name}/x0"], dt, done, amp, duration=dur) if name.startswith("nl") else None
+        assert_blocks(x, ref, ob.red2full(), 1e-11, what=(name, c), cond=cond)
+        assert abs(x[ob.n - 2] - ref[ob.n - 2]) <= 1e-12 * abs(ref[ob.n - 2])
 
 
 def test_g5_survey_anchors(golden):
@@ -149,7 +155,7 @@ def test_g6_lqr_closed_loop(golden, name):
     assert rel_err(ob.mass(), z[f"{name}/M"]) < 1e-15 and rel_err(ob.stiffness(), z[f"{name}/K"]) < 1e-15
     x = ob.rk4_feedback(np.zeros(2 * ob.n), float(z[f"{name}/dt"]), int(z[f"{name}/steps"]), z[f"{name}/gain"],
                         amp=float(z[f"{name}/amp"]))
-    assert rel_err(x, z[f"{name}/x_final"]) < 1e-9
+    assert_blocks(x, z[f"{name}/x_final"], ob.red2full(), 1e-9, what=name)
 
 
 @pytest.mark.parametrize("name", ["lin40_grav", "nl64_drag"])
@@ -172,4 +178,4 @@ def test_g7_scipy_rk45_over_oracle_rhs(golden, name):
                     atol=float(z[f"{name}/atol"]))
     assert sol.nfev == int(z[f"{name}/nfev"]) and len(sol.t) - 1 == int(z[f"{name}/accepted"])
     assert np.allclose(sol.t, z[f"{name}/t_steps"], rtol=1e-9, atol=0)
-    assert rel_err(sol.y[:, -1], z[f"{name}/x_final"]) < 1e-8
+    assert_blocks(sol.y[:, -1], z[f"{name}/x_final"], ob.red2full(), 1e-8, what=name)
