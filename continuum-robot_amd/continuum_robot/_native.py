@@ -44,7 +44,7 @@ class BeamDesc(C.Structure):
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "n_beams", "n_elem", "n_node", "n_free", "node_offset", "n_slots", "beams_per_group", "threads",
-        "pcr_levels", "pcr_levels_full", "reserved")]
+        "pcr_levels", "pcr_levels_full", "mixed_topology")]
 
 
 class InputDesc(C.Structure):
@@ -56,6 +56,7 @@ class InputDesc(C.Structure):
         ("duration", C.c_double),
         ("amp", C.c_void_p),
         ("f_held", C.c_void_p),
+        ("node_b", C.c_void_p),
     ]
 
 
@@ -99,6 +100,8 @@ def load():
     L.crb_plan_destroy.restype = None
     L.crb_plan_get_layout.argtypes = [vp, C.POINTER(Layout)]
     L.crb_plan_get_free_index.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.crb_plan_get_beam_info.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.crb_plan_get_beam_free_index.argtypes = [vp, i32, C.POINTER(C.c_int32)]
     L.crb_plan_get_pcr_tables.argtypes = [vp, _dp, _dp, _dp]
     L.crb_plan_get_slot_tables.argtypes = [vp, _dp, _dp, _dp, C.POINTER(C.c_int16), C.POINTER(C.c_int32)]
     L.crb_plan_get_mass.argtypes = [vp, _dp]
@@ -173,30 +176,52 @@ def _beam_desc(columns, node_bc, fluid_density, enable_fluid, gravity, enable_gr
 
 
 class Plan:
-    """Owner of one ``crb_plan`` (one beam topology x n_beams, one dtype, one device).
+    """Owner of one ``crb_plan`` (n_beams beams, one dtype, one device).
 
     ``columns``: the CSV columns of the beam (dict) -- coefficients shared by all beams -- or a
-    list of n_beams such dicts for per-beam coefficients (crb_plan_create_ensemble)."""
+    list of n_beams such dicts for a heterogeneous ensemble (crb_plan_create_ensemble): per-beam element columns,
+    element count and boundary conditions.  With a list, ``node_bc``, ``fluid_density``, ``enable_fluid``,
+    ``gravity`` and ``enable_gravity`` may each be a list of n_beams values too (per-beam ForceParams)."""
 
     def __init__(self, columns, n_beams=1, node_bc=None, fluid_density=0.0, enable_fluid=False,
                  gravity=(0.0, -9.81, 0.0), enable_gravity=False, corrected_axial=False, dtype="f64", device=0):
         L = load()
-        args = (node_bc, fluid_density, enable_fluid, gravity, enable_gravity, corrected_axial)
         self.dtype = {"f64": CRB_F64, "f32": CRB_F32, CRB_F64: CRB_F64, CRB_F32: CRB_F32}[dtype]
         self.device = int(device)
         h = C.c_void_p()
         if isinstance(columns, (list, tuple)):
             if len(columns) != n_beams:
                 raise ValueError("per-beam coefficients need exactly n_beams column sets")
+
+            def scalars(v, name):
+                """one value for all beams, or a sequence of n_beams values"""
+                if np.ndim(v) == 0:
+                    return lambda b: v
+                if len(v) != n_beams:
+                    raise ValueError(f"{name}: expected {n_beams} per-beam values, got {len(v)}")
+                return lambda b: v[b]
+
+            fd_of, ef_of, eg_of = (scalars(fluid_density, "fluid_density"), scalars(enable_fluid, "enable_fluid"),
+                                   scalars(enable_gravity, "enable_gravity"))
+            g = np.asarray(gravity, dtype=np.float64)
+            if g.shape not in ((3,), (n_beams, 3)):
+                raise ValueError(f"gravity: expected a 3-vector or {n_beams} of them")
+            g_of = (lambda b: g) if g.ndim == 1 else (lambda b: g[b])
+            if node_bc is None:
+                bc_of = lambda b: None  # noqa: E731
+            elif len(node_bc) == n_beams and all(np.ndim(v) == 1 for v in node_bc):
+                bc_of = lambda b: node_bc[b]  # noqa: E731   (one array per beam)
+            else:
+                bc_of = lambda b: node_bc  # noqa: E731      (one array for all beams)
             descs = (BeamDesc * n_beams)()
             self._keep = []
             for b, cols in enumerate(columns):
-                descs[b], keep = _beam_desc(cols, *args)
+                descs[b], keep = _beam_desc(cols, bc_of(b), fd_of(b), bool(ef_of(b)), g_of(b), bool(eg_of(b)), corrected_axial)
                 self._keep.append(keep)
             self.per_beam = True
             check(L.crb_plan_create_ensemble(C.byref(h), self.device, self.dtype, int(n_beams), descs))
         else:
-            d, self._keep = _beam_desc(columns, *args)
+            d, self._keep = _beam_desc(columns, node_bc, fluid_density, enable_fluid, gravity, enable_gravity, corrected_axial)
             self.per_beam = False
             check(L.crb_plan_create(C.byref(h), self.device, self.dtype, int(n_beams), C.byref(d)))
         self.h = h
@@ -205,9 +230,23 @@ class Plan:
         self.layout = lay
         for name, _ in Layout._fields_:
             setattr(self, name, getattr(lay, name))
-        fi = np.empty(self.n_free, dtype=np.int32)
+        self.mixed_topology = bool(lay.mixed_topology)
+        self.n_free0 = self.beam_info(0)[1]       # beam 0's reduced size (== n_free unless the topology is mixed)
+        fi = np.empty(self.n_free0, dtype=np.int32)
         check(L.crb_plan_get_free_index(self.h, fi.ctypes.data_as(C.POINTER(C.c_int32))))
         self.free_index = fi
+
+    def beam_info(self, beam):
+        """(n_elem, n_free) of one beam of the plan"""
+        ne, nf = C.c_int32(0), C.c_int32(0)
+        check(load().crb_plan_get_beam_info(self.h, int(beam), C.byref(ne), C.byref(nf)))
+        return int(ne.value), int(nf.value)
+
+    def beam_free_index(self, beam):
+        """reduced -> full index (3 * node + dof) of one beam"""
+        fi = np.empty(self.beam_info(beam)[1], dtype=np.int32)
+        check(load().crb_plan_get_beam_free_index(self.h, int(beam), fi.ctypes.data_as(C.POINTER(C.c_int32))))
+        return fi
 
     def __del__(self):
         try:
@@ -219,12 +258,12 @@ class Plan:
 
     # ---- inspection (host)
     def mass(self):
-        M = np.empty((self.n_free, self.n_free))
+        M = np.empty((self.n_free0, self.n_free0))
         check(load().crb_plan_get_mass(self.h, M.ctypes.data_as(_dp)))
         return M
 
     def stiffness(self):
-        K = np.empty((self.n_free, self.n_free))
+        K = np.empty((self.n_free0, self.n_free0))
         check(load().crb_plan_get_stiffness(self.h, K.ctypes.data_as(_dp)))
         return K
 

@@ -46,10 +46,30 @@ def _columns(parameters, need_fluid):
 
 
 class BeamEnsemble:
-    def __init__(self, parameters, n_beams: int, force_params: Optional[ForceParams] = None, dtype=torch.float64,
+    """B independent beams stepped together on one GPU.
+
+    ``parameters``: one parameter set (CSV path / DataFrame / dict of columns) shared by all ``n_beams`` beams, or a
+    list of ``n_beams`` of them -- a heterogeneous ensemble (SURVEY f-3): every beam has its own element columns and
+    types and may have its own element COUNT and boundary-condition column.  ``force_params`` is then one
+    ``ForceParams`` for all beams or a list of ``n_beams`` (what examples/beam_comparison_fluid.py:49-83 runs as six
+    processes -- three beams without, three with fluid -- is ONE ensemble here).
+
+    Reduced vectors ([q_red ; v_red], the reference's state ordering) are ``[B, 2 n]``.  When the beams' free-DOF
+    sets differ (``mixed_topology``), ``n`` is the largest beam's and beam b uses the first ``n_per_beam[b]`` entries
+    of each half (the rest is ignored on input and zero on output); ``beam_state(b)`` / ``pad_states`` convert."""
+
+    def __init__(self, parameters, n_beams: int, force_params=None, dtype=torch.float64,
                  device: Union[str, torch.device, int] = "cuda", corrected_axial: bool = False, node_bc=None):
-        self.force_params = force_params or ForceParams()
-        fp = self.force_params
+        per_beam_fp = isinstance(force_params, (list, tuple))
+        if per_beam_fp:
+            if not isinstance(parameters, (list, tuple)):
+                parameters = [parameters] * n_beams      # one beam description, per-beam ForceParams
+            if len(force_params) != n_beams:
+                raise ValueError("a list of ForceParams must have n_beams entries")
+            self.force_params = [fp or ForceParams() for fp in force_params]
+        else:
+            self.force_params = force_params or ForceParams()
+        fp_of = (lambda b: self.force_params[b]) if per_beam_fp else (lambda b: self.force_params)
         if dtype not in (torch.float64, torch.float32):
             raise ValueError("dtype must be torch.float64 or torch.float32")
         nat.load()  # raises if the extension was not built
@@ -62,23 +82,66 @@ class BeamEnsemble:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
         if isinstance(parameters, (list, tuple)):
-            # heterogeneous ensemble: one parameter set per beam (same topology, per-beam coefficients)
+            # heterogeneous ensemble: one parameter set per beam
             if len(parameters) != n_beams:
                 raise ValueError("a list of parameter sets must have n_beams entries")
-            self.columns = [_columns(p, fp.enable_fluid_effects) for p in parameters]
+            self.columns = [_columns(p, fp_of(b).enable_fluid_effects) for b, p in enumerate(parameters)]
         else:
-            self.columns = _columns(parameters, fp.enable_fluid_effects)
+            self.columns = _columns(parameters, fp_of(0).enable_fluid_effects)
+        fps = [fp_of(b) for b in range(n_beams)] if per_beam_fp else None
         with torch.cuda.device(self.device):   # (plan creation selects the plan's device: keep the caller's current one)
-            self.plan = nat.Plan(self.columns, n_beams=n_beams, node_bc=node_bc, fluid_density=fp.fluid_density,
-                                 enable_fluid=fp.enable_fluid_effects, gravity=fp.get_gravity_vector(),
-                                 enable_gravity=fp.enable_gravity_effects, corrected_axial=corrected_axial,
-                                 dtype="f64" if dtype == torch.float64 else "f32", device=self.device.index)
+            self.plan = nat.Plan(
+                self.columns, n_beams=n_beams, node_bc=node_bc,
+                fluid_density=[f.fluid_density for f in fps] if fps else fp_of(0).fluid_density,
+                enable_fluid=[f.enable_fluid_effects for f in fps] if fps else fp_of(0).enable_fluid_effects,
+                gravity=[f.get_gravity_vector() for f in fps] if fps else fp_of(0).get_gravity_vector(),
+                enable_gravity=[f.enable_gravity_effects for f in fps] if fps else fp_of(0).enable_gravity_effects,
+                corrected_axial=corrected_axial, dtype="f64" if dtype == torch.float64 else "f32", device=self.device.index)
         p = self.plan
         self.n_beams, self.n_elem, self.n_node, self.n = n_beams, p.n_elem, p.n_node, p.n_free
-        self.free_index = p.free_index.copy()
+        self.mixed_topology = p.mixed_topology
+        self.free_index = p.free_index.copy()                 # beam 0's (every beam's unless mixed_topology)
+        if self.mixed_topology:
+            self.free_index_per_beam = [p.beam_free_index(b) for b in range(n_beams)]
+            self.n_per_beam = np.array([fi.size for fi in self.free_index_per_beam])
+            self.n_elem_per_beam = np.array([p.beam_info(b)[0] for b in range(n_beams)])
+        else:
+            self.free_index_per_beam = [self.free_index] * n_beams
+            self.n_per_beam = np.full(n_beams, self.n)
+            self.n_elem_per_beam = np.full(n_beams, self.n_elem)
         self.state = torch.zeros((n_beams, 2, self.n_node, 4), dtype=dtype, device=self.device)
         self.time = 0.0
         self._lib = nat.load()
+
+    @classmethod
+    def from_dataframes(cls, frames: Sequence, force_params=None, **kwargs):
+        """One beam per entry of ``frames`` (DataFrames, CSV paths or column dicts -- the reference's beam files,
+        euler_bernoulli_beam.py:26-109; boundary conditions from each file's own column,
+        dynamic_beam_model.py:205-218), ``force_params`` one ForceParams or one per beam."""
+        frames = list(frames)
+        return cls(frames, len(frames), force_params=force_params, **kwargs)
+
+    # ------------------------------------------------------------------ ragged reduced vectors (mixed_topology)
+    def pad_states(self, states: Sequence) -> np.ndarray:
+        """per-beam reference state vectors [2 n_b] -> the ensemble's [B, 2 n] layout ([q_b, 0.. ; v_b, 0..])"""
+        if len(states) != self.n_beams:
+            raise ValueError("expected one state vector per beam")
+        out = np.zeros((self.n_beams, 2 * self.n))
+        for b, x in enumerate(states):
+            nb = int(self.n_per_beam[b])
+            x = np.asarray(x, dtype=np.float64)
+            if x.shape != (2 * nb,):
+                raise ValueError(f"beam {b}: expected a state of {2 * nb} entries, got {x.shape}")
+            out[b, :nb] = x[:nb]
+            out[b, self.n:self.n + nb] = x[nb:]
+        return out
+
+    def beam_state(self, b: int, x_red=None) -> np.ndarray:
+        """the reference's state vector [q_red ; v_red] of beam ``b`` (host array of 2 n_b entries)"""
+        x = self.unpack_state() if x_red is None else x_red
+        row = x[b].detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x[b])
+        nb = int(self.n_per_beam[b])
+        return np.concatenate([row[:nb], row[self.n:self.n + nb]])
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -94,11 +157,11 @@ class BeamEnsemble:
     def _ptr(t):
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
-    def reduced_index(self, node: int, param: str) -> int:
-        """Reduced position index of (node, 'u'|'w'|'phi'); KeyError when constrained or absent
+    def reduced_index(self, node: int, param: str, beam: int = 0) -> int:
+        """Reduced position index of (node, 'u'|'w'|'phi') in beam ``beam``; KeyError when constrained or absent
         (reference: EulerBernoulliBeam.get_dof_index, euler_bernoulli_beam.py:404-420)."""
         full = 3 * node + _PARAM[param]
-        hit = np.nonzero(self.free_index == full)[0]
+        hit = np.nonzero(self.free_index_per_beam[beam] == full)[0]
         if node < 0 or node >= self.n_node or hit.size == 0:
             raise KeyError(f"Invalid node/parameter combination: ({node}, {param})")
         return int(hit[0])
@@ -144,6 +207,29 @@ class BeamEnsemble:
         self.state.zero_()
         self.time = 0.0
 
+    def _impulse(self, desc, keep, impulse_amp, impulse_duration, impulse_index):
+        """Fill the impulse part of a crb_input_desc: amplitudes [B] on reduced position index ``impulse_index`` of
+        EVERY beam (-2 = each beam's own tip w, example_utilities.py:147) while t < impulse_duration."""
+        amp = self._dev(impulse_amp, (self.n_beams,))
+        nodes, dofs = [], []
+        for b in (range(self.n_beams) if self.mixed_topology else (0,)):
+            fi = self.free_index_per_beam[b]
+            idx = impulse_index if impulse_index >= 0 else fi.size + impulse_index
+            if not 0 <= idx < fi.size:
+                raise IndexError("impulse_index out of range")
+            nodes.append(int(fi[idx]) // 3)
+            dofs.append(int(fi[idx]) % 3)
+        if len(set(dofs)) != 1:
+            raise ValueError("impulse_index addresses different DOF kinds (u / w / phi) in different beams")
+        desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, nodes[0], dofs[0]
+        desc.duration = float(impulse_duration)
+        desc.amp = amp.data_ptr()
+        keep.append(amp)
+        if len(set(nodes)) > 1:       # beams of different length / boundary conditions: each forced at its own node
+            node_b = torch.as_tensor(nodes, dtype=torch.int32, device=self.device)
+            desc.node_b = node_b.data_ptr()
+            keep.append(node_b)
+
     # ------------------------------------------------------------------ the hot path
     def internal_force(self, q_red) -> torch.Tensor:
         """k(q) for every beam, reduced [B, n]."""
@@ -187,15 +273,7 @@ class BeamEnsemble:
         desc.kind = nat.CRB_INPUT_NONE
         keep = []
         if impulse_amp is not None:
-            amp = self._dev(impulse_amp, (self.n_beams,))
-            idx = impulse_index if impulse_index >= 0 else self.n + impulse_index
-            if not 0 <= idx < self.n:
-                raise IndexError("impulse_index out of range")
-            full = int(self.free_index[idx])
-            desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, full // 3, full % 3
-            desc.duration = float(impulse_duration)
-            desc.amp = amp.data_ptr()
-            keep.append(amp)
+            self._impulse(desc, keep, impulse_amp, impulse_duration, impulse_index)
         if held_force is not None:
             held = self.pack_vec(held_force)
             desc.f_held = held.data_ptr()
@@ -243,15 +321,7 @@ class BeamEnsemble:
         desc.kind = nat.CRB_INPUT_NONE
         keep = []
         if impulse_amp is not None:
-            amp = self._dev(impulse_amp, (self.n_beams,))
-            idx = impulse_index if impulse_index >= 0 else self.n + impulse_index
-            if not 0 <= idx < self.n:
-                raise IndexError("impulse_index out of range")
-            full = int(self.free_index[idx])
-            desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, full // 3, full % 3
-            desc.duration = float(impulse_duration)
-            desc.amp = amp.data_ptr()
-            keep.append(amp)
+            self._impulse(desc, keep, impulse_amp, impulse_duration, impulse_index)
         if held_force is not None:
             held = self.pack_vec(held_force)
             desc.f_held = held.data_ptr()
@@ -314,16 +384,9 @@ class BeamEnsemble:
         ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
         desc = nat.InputDesc()
         desc.kind = nat.CRB_INPUT_NONE
-        amp = None
+        keep = []
         if impulse_amp is not None:
-            amp = self._dev(impulse_amp, (self.n_beams,))
-            idx = impulse_index if impulse_index >= 0 else self.n + impulse_index
-            if not 0 <= idx < self.n:
-                raise IndexError("impulse_index out of range")
-            full = int(self.free_index[idx])
-            desc.kind, desc.node, desc.dof = nat.CRB_INPUT_IMPULSE, full // 3, full % 3
-            desc.duration = float(impulse_duration)
-            desc.amp = amp.data_ptr()
+            self._impulse(desc, keep, impulse_amp, impulse_duration, impulse_index)
         # the whole loop is one native call (crb_step_rk4_feedback issues every launch)
         work = torch.empty((int(self._lib.crb_feedback_work_bytes(self.plan.h)),), dtype=torch.uint8, device=self.device)
         t_end = C.c_double(0.0)
@@ -331,7 +394,7 @@ class BeamEnsemble:
             nat.check(self._lib.crb_step_rk4_feedback(self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps),
                                                       self._ptr(K), self._ptr(ref), C.byref(desc), self._ptr(work),
                                                       C.byref(t_end), self._stream()))
-        self._keep = [amp, K, ref, work]
+        self._keep = keep + [K, ref, work]
         self.time = float(t_end.value)
         return self.time
 
@@ -343,5 +406,9 @@ class BeamEnsemble:
         return out
 
     def tip_displacement(self) -> torch.Tensor:
-        """w of the last node for every beam (the examples' 'tip displacement', lqr_control.py:168)."""
-        return self.gather(self.n_elem, "w")
+        """w of the last node of every beam (the examples' 'tip displacement', lqr_control.py:168)."""
+        if len(set(self.n_elem_per_beam.tolist())) == 1:
+            return self.gather(self.n_elem, "w")
+        rows = torch.arange(self.n_beams, device=self.device)      # beams of different length: each beam's own last node
+        nodes = torch.as_tensor(self.n_elem_per_beam, device=self.device)
+        return self.state[rows, 0, nodes, 1].clone()

@@ -18,12 +18,19 @@ namespace crb {
 struct AsmParams {
     const double* L; const double* E; const double* I; const double* rho; const double* A;  // [n_elem]
     const uint8_t* nonlinear;   // [n_elem]
-    const uint8_t* free_dof;    // [3*n_node]
+    const uint8_t* free_dof;    // [3*n_node]                 (+ beam * free_stride: per-beam boundary conditions)
     const double* wet; const double* cd;  // [n_elem] or null
-    const GravTab* grav;        // [S] index table (host-built topology)
+    const GravTab* grav;        // [S] index table (host-built topology)   (+ beam * grav_stride)
     double fluid_density;
     uint32_t flags;
     int n_elem, n_node, off, S, levels_full;
+    // per-beam topology / force parameters of a mixed ensemble (SURVEY f-3); null / 0 = the shared values above.
+    // A beam shorter than the plan (n_elem_b[beam] < n_elem) ends in padding nodes: every DOF constrained
+    // (free_dof = 0), no element, identity mass block -- they take no part in anything.
+    const int32_t* n_elem_b;    // [nb]
+    const double* fluid_density_b;  // [nb]
+    const uint32_t* flags_b;    // [nb]
+    size_t free_stride, grav_stride;
     void* slot_out;             // SlotConst<T>[nb][S]
     double* lv64; void* lvT;    // [nb][levels_full][S][10]   (lv64 may be null)
     double* fin64_all;          // [levels_full+1][S][6] final inverse after k levels (beam 0 only; may be null)
@@ -47,8 +54,11 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
     const int j = threadIdx.x;
     const int beam = blockIdx.x;
     const bool valid = j < p.S;
-    const int node = j + p.off, ne = p.n_elem, nn = p.n_node;
-    auto fm = [&](int nd, int c) { return nd >= 0 && nd < nn && p.free_dof[3 * nd + c] != 0; };
+    const int node = j + p.off, ne = p.n_elem_b ? p.n_elem_b[beam] : p.n_elem, nn = p.n_node;
+    const uint8_t* free_dof = p.free_dof + size_t(beam) * p.free_stride;
+    const uint32_t flags = p.flags_b ? p.flags_b[beam] : p.flags;
+    const double fluid_density = p.fluid_density_b ? p.fluid_density_b[beam] : p.fluid_density;
+    auto fm = [&](int nd, int c) { return nd >= 0 && nd < nn && free_dof[3 * nd + c] != 0; };
     const size_t eo = size_t(beam) * p.elem_stride;
     const double *pL = p.L + eo, *pE = p.E + eo, *pI = p.I + eo, *pRho = p.rho + eo, *pA = p.A + eo;
     const uint8_t* pNl = p.nonlinear + eo;
@@ -64,7 +74,7 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
         SlotConst<T> sc;
         const int e = node - 1;
         int kind = KIND_NONE;
-        if (e >= 0) {
+        if (e >= 0 && e < ne) {
             kind = pNl[e] ? KIND_NONLINEAR : KIND_LINEAR;
             elem_coef_build<T>(sc.elem, kind, pL[e], pE[e], pI[e], pA[e]);
         } else {
@@ -73,17 +83,17 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
         for (int c = 0; c < 3; ++c) sc.mask[c] = fm(node, c) ? T(1) : T(0);
         sc.pad0 = T(0);
         sc.drag = T(0);
-        if ((p.flags & 1u) && fm(node, 1)) {
+        if ((flags & 1u) && fm(node, 1)) {
             const int row = node < ne ? node : ne - 1;
-            sc.drag = T(0.5 * p.fluid_density * pCd[row] * pWet[row]);
+            sc.drag = T(0.5 * fluid_density * pCd[row] * pWet[row]);
         }
-        sc.half_mass = ((p.flags & 2u) && j < ne) ? T(0.5 * (pRho[j] * pA[j] * pL[j])) : T(0);
-        sc.grav = p.grav[j];
+        sc.half_mass = ((flags & 2u) && j < ne) ? T(0.5 * (pRho[j] * pA[j] * pL[j])) : T(0);
+        sc.grav = p.grav[size_t(beam) * p.grav_stride + j];
         static_cast<SlotConst<T>*>(p.slot_out)[tab + j] = sc;
 
         // ---- mass matrix, node-block form, with the boundary-condition masks
         const int el = node - 1, er = node;
-        if (el >= 0) mass_add_as_left_elem(cur, pL[el], pRho[el] * pA[el], j >= 1);
+        if (el >= 0 && el < ne) mass_add_as_left_elem(cur, pL[el], pRho[el] * pA[el], j >= 1);
         if (er < ne) mass_add_as_right_elem(cur, pL[er], pRho[er] * pA[er]);
         const bool hl = j >= 1, hr = j + 1 < p.S;
         mass_apply_masks(cur, fm(node, 0), fm(node, 1), fm(node, 2), hl && fm(node - 1, 0), hl && fm(node - 1, 1),

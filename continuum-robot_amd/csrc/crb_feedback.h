@@ -337,14 +337,20 @@ __host__ __device__ constexpr size_t feedback_lds_bytes(int n2) {
 // ------------------------------------------------------------------ layout conversion
 // reduced [B][rows*n_free] <-> device [B][rows][n_node][4]; free_index[r] = 3*node + dof
 template <typename T, bool PACK>
-__global__ void crb_pack_kernel(const int32_t* free_index, int n_free, int n_node, int rows, int B, const T* src_red,
-                                T* dev, T* dst_red) {
+__global__ void crb_pack_kernel(const int32_t* free_index, size_t fi_stride, int n_free, int n_node, int rows, int B,
+                                const T* src_red, T* dev, T* dst_red) {
+    // fi_stride != 0: per-beam reduced -> full maps [B][n_free], -1 = padding of a beam with fewer free DOFs than the
+    // ensemble's largest (mixed boundary conditions / lengths): ignored on pack, zero on unpack
     const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const size_t per_beam = size_t(rows) * n_free;
     if (i >= size_t(B) * per_beam) return;
     const size_t b = i / per_beam, rem = i - b * per_beam;
     const int row = int(rem / n_free), r = int(rem - size_t(row) * n_free);
-    const int fi = free_index[r];
+    const int fi = free_index[b * fi_stride + r];
+    if (fi < 0) {
+        if (!PACK) dst_red[i] = T(0);
+        return;
+    }
     const size_t d = (b * rows + row) * size_t(n_node) * 4 + size_t(fi / 3) * 4 + (fi % 3);
     if (PACK) dev[d] = src_red[i];
     else dst_red[i] = dev[d];

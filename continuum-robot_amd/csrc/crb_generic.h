@@ -71,9 +71,11 @@ struct KParams {
     int lognw;                 // log2(wavefronts per beam); 0 when a wave holds whole beams
     uint32_t flags;
     int imp_slot, imp_dof;
+    const int32_t* imp_node_b; // [B] per-beam impulse node (mixed ensembles) or nullptr: imp_slot for every beam
     double duration, t0, dt;
     int n_steps;
     T gx, gy;
+    const T* gvec;             // [B][2] per-beam gravity vector (mixed ensembles), or nullptr: gx, gy for every beam
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
@@ -113,7 +115,7 @@ __host__ __device__ constexpr size_t lds_bytes(int NT) {
 
 // Where a thread sits: slot j of beam-in-group g, and how to find other slots of its beam.
 struct Topo {
-    int t, lane, j, S, lognw, nwm1, base;
+    int t, lane, j, S, lognw, nwm1, base, beam;
     bool valid;
     // thread id (LDS index) of slot jj of this thread's beam
     __device__ __forceinline__ int thread_of(int jj) const { return base + ((jj & nwm1) << 6) + (jj >> lognw); }
@@ -186,7 +188,9 @@ __device__ __forceinline__ void stage_accel(const KParams<T>& p, const Lds<T>& l
         T phi = T(0);
         if (ia >= 0) phi = lds.q[(ia & 3) * NT + tp.thread_of(ia >> 2)];
         if (ib >= 0) phi = T(0.5) * (phi + lds.q[(ib & 3) * NT + tp.thread_of(ib >> 2)]);
-        gravity_segment<T>(phi, p.gx, p.gy, sc.half_mass, gseg);
+        T gx = p.gx, gy = p.gy;
+        if (p.gvec) { gx = p.gvec[2 * size_t(tp.beam)]; gy = p.gvec[2 * size_t(tp.beam) + 1]; }   // (per-beam ForceParams)
+        gravity_segment<T>(phi, gx, gy, sc.half_mass, gseg);
     }
 
     // -- 2. the right neighbour's left-node half of its element force (+ segment gravity via LDS)
@@ -269,6 +273,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
     }
     const int beam = blockIdx.x * p.G + g;
     tp.valid = (g < p.G) && (tp.j < p.S) && (beam < p.B);
+    tp.beam = tp.valid ? beam : 0;
     if (!tp.valid) {
         // padding thread: an isolated dummy node (no neighbour at any stride, all coefficients 0).
         // lognw stays the launch value: the barrier / shuffle choice must be workgroup-uniform.
@@ -326,7 +331,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
 #pragma unroll
             for (int c = 0; c < 3; ++c) uh[c] = p.u_held[uoff + c];
         }
-        if (p.amp && tp.j == p.imp_slot) amp = p.amp[beam];
+        if (p.amp && tp.j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
     }
 
     if (MODE == MODE_STAGE) {

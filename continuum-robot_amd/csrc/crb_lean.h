@@ -78,6 +78,15 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 #ifndef CRB_SOA
 #define CRB_SOA 1
 #endif
+// components (0..3) of the lane+-4 exchange that travel by ds_bpermute instead of four chained DPP moves per half:
+// the kernel is bound by vector-ALU issue, the LDS pipe has slack -- moving PART of the widest shift there balances
+// the two (all 12 ds_bpermute: LDS-issue-bound again, measured in round 1)
+#ifndef CRB_BPERM_C
+#define CRB_BPERM_C 0
+#endif
+#ifndef CRB_BPERM_C2   // the same for the lane+-2 exchange (two chained DPP moves per half)
+#define CRB_BPERM_C2 0
+#endif
 #define CRB_SETPRIO(v) do { if ((v) >= 0) __builtin_amdgcn_s_setprio((v) < 0 ? 0 : (v)); } while (0)
 template <typename T, int D>
 __device__ __forceinline__ T lane_lower(T x, int lane) {
@@ -119,7 +128,10 @@ __device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
 // Levels whose stride stays inside the workgroup's waves-per-beam interleave (l < LOGNW) go through LDS
 // columns + a barrier, the others are in-wave lane shifts.  A missing neighbour contributes through a
 // multiplier that is exactly 0, so whatever finite value the shift returns there is harmless.
-template <typename T, int LV, int LOGNW>
+// ISOLATE (packed beams: several beams share the wave): what a lane shift drags across a beam boundary is replaced
+// by 0 with a select -- a multiplier of exactly 0 would turn a neighbouring beam's Inf/NaN into NaN here, and
+// the reference's beams are independent (a diverged beam must not take its wave-mates with it).
+template <typename T, int LV, int LOGNW, bool ISOLATE = false>
 __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* ldsB, int t, int lane, int j, int S,
                                                  bool valid, T r[3], T a[3]) {
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
@@ -143,12 +155,24 @@ __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* 
             for (int c = 0; c < 3; ++c) {
                 switch (l - LOGNW) {
                     case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
-                    case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
-                    case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
+                    case 1:
+                        if (c < CRB_BPERM_C2) { rlo[c] = __shfl(r[c], lane - 2, 64); rhi[c] = __shfl(r[c], lane + 2, 64); }
+                        else { rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); }
+                        break;
+                    case 2:
+                        if (c < CRB_BPERM_C) { rlo[c] = __shfl(r[c], lane - 4, 64); rhi[c] = __shfl(r[c], lane + 4, 64); }
+                        else { rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); }
+                        break;
                     case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
                     case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
                     default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
                 }
+            }
+            if (ISOLATE) {
+                const int st = 1 << l;
+                const bool lo_ok = valid && j - st >= 0, hi_ok = valid && j + st < S;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { rlo[c] = lo_ok ? rlo[c] : T(0); rhi[c] = hi_ok ? rhi[c] : T(0); }
             }
         }
         pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
@@ -223,8 +247,28 @@ __device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool co
 // exchanges stay DPP lane shifts; what a shift drags across a beam boundary is cancelled by 0/1 masks on the
 // three terms where no zero multiplier does it already (q of the left node, f_left of the right neighbours).
 template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false, bool PACK = false>
-// fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: 3 waves/SIMD (168 VGPRs; 4 waves/SIMD spills)
-__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_step_lean_kernel(const KParams<T> p) {
+// fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: the headline shape (<= 4 levels, no gravity, no held
+// input) fits 4 waves/SIMD (128 VGPRs; three 8-byte addresses spill, outside the step loop: config 4 runs 8.1e10
+// element-steps/s at 4 waves against 6.6e10 at 3), the other fp32 instantiations keep 3 waves/SIMD (168 VGPRs)
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? ((LV <= 4 && !GRAV && !HELD) ? 4 : 3) : 2)
+crb_step_lean_kernel(const KParams<T> p_formal) {
+    // The launch parameters are read through the kernarg pointer, which is "laundered" (CRB_FRESH) at the top of
+    // every beam and again after the step loop: what the beam prologue / epilogue need (pointers, strides, sizes) is
+    // then re-read from the kernarg segment by a few scalar loads instead of staying live in SGPRs across the step
+    // loop.  That loop keeps ~36 SGPRs of fp64 polynomial constants; with the walk-over-beams loop around it the
+    // scalar file overflowed (28 spills) and the scheduler fell back to a serialised LDS schedule: 28.4 -> 32.4 us/step.
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) KParams<T>* KP;
+    KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();   // the explicit arguments start at offset 0 of the segment
+    (void)p_formal;
+#define CRB_FRESH(ptr) asm volatile("" : "+s"(ptr))
+#define CRB_PARAMS(ptr) (*(const KParams<T>*)(ptr))
+#else   // (host pass: only the stub is emitted; keep the body well-formed)
+    const KParams<T>* kp = &p_formal;
+#define CRB_FRESH(ptr) (void)(ptr)
+#define CRB_PARAMS(ptr) (*(ptr))
+#endif
+    KParams<T> p = CRB_PARAMS(kp);
     static_assert(!PACK || LOGNW == 0, "packed beams live inside one wave");
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N, RV = LeanRec<T>::V;
@@ -241,15 +285,12 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     const int S = p.S;
     const int pg = PACK ? lane / S : 0;                         // beam of this lane inside the wave
     const int j = PACK ? lane - pg * S : ((lane << LOGNW) | wave);
-    const int beam = PACK ? int(blockIdx.x) * p.G + pg : int(blockIdx.x);
-    const bool valid = PACK ? (pg < p.G && beam < p.B) : (j < S);
-    // 0/1 factors for what a lane shift drags in from the neighbouring beam of a packed wave
-    const T mL = (valid && j >= 1) ? T(1) : T(0), mR1 = (valid && j + 1 < S) ? T(1) : T(0), mR2 = (valid && j + 2 < S) ? T(1) : T(0);
+    const bool has_slot = PACK ? (pg < p.G) : (j < S);          // this thread carries a slot (of some beam)
     auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
     // LDS positions of the stride-1 / stride-2 neighbours (NULLT outside the beam)
-    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
-    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
-    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+    const int t_l1 = (has_slot && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (has_slot && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (has_slot && j + 2 < S) ? thread_of(j + 2) : NULLT;
 
     if (LOGNW > 0 && t == 0) {  // zero the "no neighbour" slots once
 #pragma unroll
@@ -263,59 +304,76 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             for (int c = 0; c < 3; ++c) ldsB[(size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
     }
 
-    // ---- per-thread constants
+    // ---- per-thread constants: element pack, drag factor, the thread's rows of the solve tables.  Plans whose
+    // beams share one table set load them ONCE per workgroup; the workgroup then walks over its beams (the grid is
+    // sized to what is resident, crb_lean.hip): at 4096 x 256 the table prologue is 112 KB per workgroup from L2,
+    // 460 MB per launch if every beam's workgroup repeats it -- 43 us, the whole fixed cost of a launch.
+    const bool shared_tables = p.slot_stride == 0 && p.lv_stride == 0 && p.fin_stride == 0;
     ElemCoef<T> ec;
     T dragc = T(0);
     SolveCoef<T, LV> cf;
-    if (valid) {
-        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];
-        ec = sc.elem;
-        dragc = (p.flags & 1u) ? sc.drag : T(0);
-#pragma unroll
-        for (int l = 0; l < LV; ++l) {
-            const T* src = p.pcr_levels + size_t(beam) * p.lv_stride + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
-#pragma unroll
-            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(beam) * p.fin_stride + size_t(j) * PCR_FINAL_VALS + k];
-    } else {
-        ec.kind = KIND_NONE;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ec.c[k] = T(0);
-#pragma unroll
-        for (int l = 0; l < LV; ++l)
-#pragma unroll
-            for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
-    }
-    const bool corrected = (p.flags & 4u) != 0;
     // GRAV: gravity on the canonical cantilever (only node 0 constrained), where the reference's reduced-index
     // addressing (gravity_forces.py:104-146) is nearest-neighbour: segment j averages the rotations of slots j
     // and j+1 (slot j alone at the tip) and loads slots j and j+1.  A thread evaluates segment j AND segment
     // j-1 itself (it knows phi of slots j-1, j, j+1), so gravity needs no exchange of its own.
-    T hm_own = T(0), hm_left = T(0), phiR = T(0);
-    const bool has_right = valid && j + 1 < S;
-    if (GRAV && valid) {
-        hm_own = p.slot[size_t(beam) * p.slot_stride + j].half_mass;
-        if (j >= 1) hm_left = p.slot[size_t(beam) * p.slot_stride + j - 1].half_mass;
-    }
+    T hm_own = T(0), hm_left = T(0);
+    auto load_tables = [&](int beam) {
+        if (has_slot) {
+            const SlotConst<T>* st = p.slot + size_t(beam) * p.slot_stride;
+            const SlotConst<T>& sc = st[j];
+            ec = sc.elem;
+            dragc = (p.flags & 1u) ? sc.drag : T(0);
+            if (GRAV) { hm_own = sc.half_mass; hm_left = j >= 1 ? st[j - 1].half_mass : T(0); }
+#pragma unroll
+            for (int l = 0; l < LV; ++l) {
+                const T* src = p.pcr_levels + size_t(beam) * p.lv_stride + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = p.pcr_final[size_t(beam) * p.fin_stride + size_t(j) * PCR_FINAL_VALS + k];
+        } else {
+            ec.kind = KIND_NONE;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ec.c[k] = T(0);
+#pragma unroll
+            for (int l = 0; l < LV; ++l)
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
+        }
+    };
+    if (shared_tables) load_tables(0);
+    const bool corrected = (p.flags & 4u) != 0;
+    const T dt = T(p.dt), hdt = T(0.5 * p.dt), dt6 = T(p.dt / 6.0);
+    const size_t plane = size_t(p.n_node) * 4;
+    const int n_groups = PACK ? (p.B + p.G - 1) / p.G : p.B;
+
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    CRB_FRESH(kp);
+    p = CRB_PARAMS(kp);
+    const int beam = PACK ? grp * p.G + pg : grp;
+    const bool valid = has_slot && (!PACK || beam < p.B);
+    const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S, has_right2 = valid && j + 2 < S;
+    if (!shared_tables) load_tables(valid ? beam : 0);
+    T phiR = T(0);
+    T gx = p.gx, gy = p.gy;
+    if (GRAV && p.gvec && valid) { gx = p.gvec[2 * size_t(beam)]; gy = p.gvec[2 * size_t(beam) + 1]; }   // per-beam ForceParams
 
     // ---- state
     const size_t node = size_t(valid ? j + p.off : 0);
-    const size_t plane = size_t(p.n_node) * 4;
-    const size_t xoff = size_t(beam) * 2 * plane + node * 4;
+    const size_t xoff = size_t(valid ? beam : 0) * 2 * plane + node * 4;
     T xq[3] = {T(0), T(0), T(0)}, xv[3] = {T(0), T(0), T(0)};
     T amp = T(0);
     if (valid) {
-        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];
+        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];   // (masks are not kept in registers)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             xq[c] = p.x[xoff + c] * sc.mask[c];
             xv[c] = p.x[xoff + plane + c] * sc.mask[c];
         }
-        if (p.amp && j == p.imp_slot) amp = p.amp[beam];
+        if (p.amp && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
     }
     T uh[3] = {T(0), T(0), T(0)};
     if (HELD && valid) {
@@ -329,7 +387,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             qL[c] = lane_lower<T, 1>(xq[c], lane);  // lane 0 reads 0 = clamped / absent root
-            if (PACK) qL[c] *= mL;
+            if (PACK) qL[c] = has_left ? qL[c] : T(0);   // (a select: the neighbouring beam may hold Inf/NaN)
         }
         if (GRAV) phiR = lane_higher<T, 1>(xq[2], lane);
     } else {
@@ -342,7 +400,6 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         __syncthreads();
     }
 
-    const T dt = T(p.dt), hdt = T(0.5 * p.dt), dt6 = T(p.dt / 6.0);
     double tc = p.t0;
     T accq[3], accv[3], sq[3], sv[3];  // RK4 accumulators and stage state
     for (int step = 0; step < p.n_steps; ++step) {
@@ -379,13 +436,13 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             pp[1] += drag_force<T>(dragc, sv[1]);
             if (GRAV) {
                 T g_own[2], g_left[2];
-                gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
+                gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], gx, gy, hm_own, g_own);
                 if (LOGNW == 0) {  // segment j-1 IS the left lane's own segment: take its result (bit-identical), one sincos less
                     g_left[0] = lane_lower<T, 1>(g_own[0], lane);
                     g_left[1] = lane_lower<T, 1>(g_own[1], lane);
-                    if (PACK) { g_left[0] *= mL; g_left[1] *= mL; }
+                    if (PACK) { g_left[0] = has_left ? g_left[0] : T(0); g_left[1] = has_left ? g_left[1] : T(0); }
                 } else {
-                    gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+                    gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), gx, gy, hm_left, g_left);
                 }
                 pp[0] += g_own[0] + g_left[0];
                 pp[1] += g_own[1] + g_left[1];
@@ -402,10 +459,13 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                     if (GRAV && c == 2) phiR = lane_higher<T, 1>(qn[2], lane);
                     qL[c] = lane_lower<T, 1>(qn[c], lane);
                     rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
-                    if (PACK) {
-                        qL[c] *= mL;
-                        r[c] = pp[c] - mR1 * lane_higher<T, 1>(fl[c], lane);
-                        rhi[c] = lane_higher<T, 1>(pp[c], lane) - mR2 * lane_higher<T, 2>(fl[c], lane);
+                    if (PACK) {   // selects, not 0/1 factors: a neighbouring beam's Inf/NaN must not leak (0 * NaN = NaN)
+                        const T fl_r1 = lane_higher<T, 1>(fl[c], lane), fl_r2 = lane_higher<T, 2>(fl[c], lane);
+                        const T pp_r1 = lane_higher<T, 1>(pp[c], lane);
+                        qL[c] = has_left ? qL[c] : T(0);
+                        rlo[c] = has_left ? rlo[c] : T(0);
+                        r[c] = pp[c] - (has_right ? fl_r1 : T(0));
+                        rhi[c] = has_right ? pp_r1 - (has_right2 ? fl_r2 : T(0)) : T(0);
                     } else {
                         r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
                         rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
@@ -462,7 +522,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 
             // -- remaining reduction levels and the final block inverse
             T a[3];
-            lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
+            lean_reduce_tail<T, LV, LOGNW, PACK>(cf, ldsB, t, lane, j, S, valid, r, a);
 
             // -- RK4 bookkeeping
 #pragma unroll
@@ -490,6 +550,8 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             }
         }
     }
+    CRB_FRESH(kp);
+    p = CRB_PARAMS(kp);
     if (valid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -497,6 +559,11 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             p.x[xoff + plane + c] = xv[c];
         }
     }
+    // (the next beam's first LDS writes come after barriers that follow this beam's last LDS reads: LOGNW >= 2 the
+    //  level-1 exchange, LOGNW == 1 the alternating round-A buffers + the two barriers of the first-stage q exchange)
+    }
+#undef CRB_FRESH
+#undef CRB_PARAMS
 }
 
 // ------------------------------------------------------------------ lean stage kernel
@@ -613,7 +680,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 uin[c] = ru[c];
             }
             if (GRAV && has_right) phiR = p.xs[xoff + 4 + 2];
-            if (p.amp && j == p.imp_slot) amp = p.amp[beam];
+            if (p.amp && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
         }
         // ---- forces on this node from its own element, drag, gravity, inputs
         T fl[3], fr[3];
@@ -628,12 +695,14 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         pp[1] += drag_force<T>(dragc, sv[1]);
         if (GRAV) {
             T g_own[2], g_left[2];
-            gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], p.gx, p.gy, hm_own, g_own);
+            T gx = p.gx, gy = p.gy;
+            if (p.gvec) { gx = p.gvec[2 * size_t(beam)]; gy = p.gvec[2 * size_t(beam) + 1]; }   // per-beam ForceParams
+            gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], gx, gy, hm_own, g_own);
             if (LOGNW == 0) {  // (as in the stepper: the left lane's own segment)
                 g_left[0] = lane_lower<T, 1>(g_own[0], lane);
                 g_left[1] = lane_lower<T, 1>(g_own[1], lane);
             } else {
-                gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), p.gx, p.gy, hm_left, g_left);
+                gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), gx, gy, hm_left, g_left);
             }
             pp[0] += g_own[0] + g_left[0];
             pp[1] += g_own[1] + g_left[1];

@@ -1,4 +1,6 @@
 // crb_lean.hip -- instantiations and launch of crb_step_lean_kernel for ONE dtype (-DCRB_LEAN_T=double|float).
+#include <cstdlib>
+
 #include "crb_lean_launch.h"
 
 #ifndef CRB_LEAN_T
@@ -9,16 +11,39 @@ namespace crb {
 namespace {
 typedef CRB_LEAN_T T;
 
+// Workgroups a launch of `kernel` keeps resident on the device (CUs x workgroups per CU by the occupancy query).
+template <typename K>
+int resident_groups(K kernel, int threads, size_t smem) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, smem) != hipSuccess || cus < 1 || per_cu < 1)
+        return 0;
+    return cus * per_cu;
+}
+
 template <int LV, int LOGNW, bool GRAV, int EM, bool HELD, bool PACK = false>
 hipError_t one_held(const KParams<T>& k, int n_beams, hipStream_t st) {
-    const dim3 grid(PACK ? (n_beams + k.G - 1) / k.G : n_beams), block(64 << LOGNW);
+    const int groups = PACK ? (n_beams + k.G - 1) / k.G : n_beams;
     const size_t smem = lean_lds_bytes<T>(64 << LOGNW, LOGNW);
+    auto kernel = crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD, PACK>;
     if (smem > 64 * 1024) {  // dynamic LDS above 64 KiB is opt-in per kernel (the CU has 160 KiB)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD, PACK>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((crb_step_lean_kernel<T, LV, LOGNW, GRAV, EM, HELD, PACK>), grid, block, smem, st, k);
+    // Shared-table plans: a workgroup loads its rows of the solve tables once and walks over several beams, so the
+    // grid is what the device keeps resident, split evenly (4096 beams = 8 beams for each of 512 workgroups).
+    // Per-beam tables are reloaded per beam anyway: one workgroup per beam, dispatched by the hardware.
+    int grid = groups;
+    const bool shared = k.slot_stride == 0 && k.lv_stride == 0 && k.fin_stride == 0;
+    static int resident = -1;   // (per instantiation; every device of a node is the same part)
+    if (shared && std::getenv("CRB_LEAN_NO_WALK") == nullptr) {
+        if (resident < 0) resident = resident_groups(kernel, 64 << LOGNW, smem);
+        if (resident > 0 && groups > resident) {
+            const int rounds = (groups + resident - 1) / resident;
+            grid = (groups + rounds - 1) / rounds;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 << LOGNW), smem, st, k);
     return hipGetLastError();
 }
 template <int LV, int LOGNW, bool GRAV, int EM>
@@ -105,6 +130,15 @@ hipError_t rk45_by_nw(const KParams<T>& k, const Rk45Params& q, int n, int lognw
 }
 }  // namespace
 
+// The instantiations are spread over translation units that build in parallel (Makefile: -DCRB_LEAN_PART=1|2|3 per
+// dtype; undefined = everything in one unit, the `make fast` tuning build): 1 = stepper without gravity (+ the
+// dispatcher), 2 = stepper with nearest-neighbour gravity, 3 = one-stage kernel and RK45 with the lean RHS.
+#ifndef CRB_LEAN_PART
+#define CRB_LEAN_PART 0
+#endif
+hipError_t launch_lean_grav(const KParams<T>& k, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st);
+
+#if CRB_LEAN_PART == 0 || CRB_LEAN_PART == 3
 hipError_t launch_rk45_lean(const KParams<T>& k, const Rk45Params& q, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st) {
 #ifdef CRB_FAST_BUILD
     return hipErrorInvalidValue;
@@ -119,17 +153,32 @@ hipError_t launch_rk45_lean(const KParams<T>& k, const Rk45Params& q, int n_beam
 #endif
 }
 
+#endif
+
+#if CRB_LEAN_PART == 0 || CRB_LEAN_PART == 2
+hipError_t launch_lean_grav(const KParams<T>& k, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    return hipErrorInvalidValue;
+#else
+    return by_lv<true, false>(k, n_beams, levels, lognw, elem_mode, st);
+#endif
+}
+#endif
+
+#if CRB_LEAN_PART == 0 || CRB_LEAN_PART == 1
 hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st) {
 #ifdef CRB_FAST_BUILD  // kernel-tuning build (make fast): only the config-3 instance
     if (sizeof(T) == 8 && levels == 5 && lognw == 2 && !grav && elem_mode == EM_NONLINEAR)
         return one<5, 2, false, EM_NONLINEAR>(k, n_beams, st);
     return hipErrorInvalidValue;
 #else
-    return grav ? by_lv<true, false>(k, n_beams, levels, lognw, elem_mode, st)
+    return grav ? launch_lean_grav(k, n_beams, levels, lognw, elem_mode, st)
                 : by_lv<false, false>(k, n_beams, levels, lognw, elem_mode, st);
 #endif
 }
+#endif
 
+#if CRB_LEAN_PART == 0 || CRB_LEAN_PART == 3
 hipError_t launch_stage_lean(const KParams<T>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st) {
 #ifdef CRB_FAST_BUILD  // kernel-tuning build: the config-5 instance (128 linear elements + gravity, fp64)
     if (sizeof(T) == 8 && levels == 5 && lognw == 1 && grav && elem_mode == EM_LINEAR)
@@ -140,4 +189,5 @@ hipError_t launch_stage_lean(const KParams<T>& k, int n_groups, int levels, int 
                 : by_lv<false, true>(k, n_groups, levels, lognw, elem_mode, st);
 #endif
 }
+#endif
 }  // namespace crb

@@ -21,6 +21,7 @@ struct Rk45Params {
     double* h_io;      // [B] in: first step (<= 0: choose like scipy), out: next step suggestion
     int32_t* stats;    // [B][4] accepted, rejected, nfev, status (0 ok, 1 step too small)
     int n_state;       // 2 * n_free: size of the reference's state vector (the error norm's N)
+    const int32_t* n_state_b;   // [B] per-beam sizes (mixed ensembles) or nullptr
     int max_steps;     // safety bound on attempted steps
     // dense output of ONE DOF on the uniform grid t_eval[k] = eval_t0 + k*eval_dt, k < n_eval (solve_ivp's
     // t_eval): after every accepted step the grid points in (t_old, t_new] -- plus t_eval[0] == t0 -- are
@@ -70,6 +71,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
     if (p.lognw == 0) { tp.j = tp.t; tp.base = 0; }
     else { tp.j = (tp.lane << p.lognw) + (tp.t >> 6); tp.base = 0; }
     const int beam = blockIdx.x;
+    tp.beam = beam;
     tp.valid = tp.j < p.S;
     if (!tp.valid) { tp.j = 0; tp.S = 1; tp.base = tp.t; tp.nwm1 = 0; }
     const bool valid = tp.valid;
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
 #pragma unroll
             for (int c = 0; c < 3; ++c) uh[c] = p.u_held[uoff + c];
         }
-        if (p.amp && tp.j == p.imp_slot) amp = p.amp[beam];
+        if (p.amp && tp.j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
     }
     // lean RHS: the 14*NT values in front of Ks hold its exchange columns ([3 + 6 + 3][NT + 1] incl. the zero
     // "no neighbour" entries)
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) s += v[c] * v[c];
-        return sqrt(block_sum<T>(s, red, NT, t, 0, 0, false) / double(q.n_state));
+        return sqrt(block_sum<T>(s, red, NT, t, 0, 0, false) / double(q.n_state_b ? q.n_state_b[beam] : q.n_state));
     };
 
     // Dormand-Prince tableau (scipy RK45.A / .B / .C / .E)

@@ -35,8 +35,16 @@ struct crb_plan {
     uint32_t flags = 0;
     int elem_mode = 0;           // EM_* (crb_generic.h)
     double gx = 0, gy = 0;
-    std::vector<int32_t> free_index;  // reduced -> full
+    std::vector<int32_t> free_index;  // reduced -> full   (beam 0; every beam of a uniform-topology plan)
     std::vector<int32_t> full2red;    // full -> reduced or -1
+    // mixed ensembles (SURVEY f-3): beams that differ in n_elem / boundary conditions / force parameters
+    bool mixed_topology = false;      // the beams' free-DOF sets differ: reduced vectors are padded to n_free (the maximum)
+    std::vector<int32_t> beam_n_elem, beam_n_free;        // [B] (empty for uniform plans)
+    std::vector<std::vector<int32_t>> beam_free_index;    // [B][n_free_b] (empty for uniform plans)
+    std::vector<uint8_t> any_free;    // [3 n_node]: DOF free in at least one beam
+    size_t free_index_stride = 0;     // d_free_index is [B][n_free] (padded with -1) when != 0
+    void* d_gvec = nullptr;           // [B][2] per-beam gravity vector in the plan dtype, or null (shared gx, gy)
+    int32_t* d_n_state = nullptr;     // [B] 2 * n_free_b, or null
     std::vector<double> h_levels, h_final, h_norms, h_mass, h_stiff;
     int first_nonlinear = -1;
     std::vector<crb::SlotConst<double>> h_slots;
@@ -74,7 +82,7 @@ struct DevBuf {
 };
 
 void mass_from_blocks(crb_plan* p, const std::vector<NodeBlocks>& blk) {
-    const int n = p->n_free, S = p->S;
+    const int n = int(p->free_index.size()), S = p->S;   // (beam 0's reduced size; n_free is the ensemble's maximum)
     p->h_mass.assign(size_t(n) * n, 0.0);
     auto put = [&](int fr, int fc, double v) {
         const int r = p->full2red[fr], c = p->full2red[fc];
@@ -111,25 +119,49 @@ int pick_levels(crb_plan* p) {
 // Runs crb_assemble_kernel on the plan's device (one workgroup per described beam) and fills both
 // the device tables the steppers load and, for beam 0, the host copies the crb_plan_get_* inspectors
 // return.  nd == 1: coefficients shared by all beams of the plan; nd == n_beams: per-beam coefficients.
+// Integer topology of one beam inside a plan of n_node nodes (built on the host): free-DOF flags (padding nodes
+// beyond the beam's own last node are fully constrained), the reduced <-> full maps and the gravity index table.
+struct BeamTopo {
+    int n_elem = 0, n_free = 0;
+    bool canonical_gravity = false;
+    std::vector<uint8_t> free_dof;      // [3 n_node]
+    std::vector<int32_t> full2red, free_index;
+    std::vector<GravTab> grav;          // [S]
+};
+
 template <typename T>
 int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::vector<SlotConst<double>>& slots,
-                    const std::vector<uint8_t>& free_dof) {
-    const int S = p->S, ne = p->n_elem, lf = p->levels_full;
+                    const std::vector<const BeamTopo*>& topo /* [nd] */, bool per_beam_topo) {
+    const int S = p->S, ne = p->n_elem, lf = p->levels_full, nn = p->n_node;
     const crb_beam_desc* d = descs;
-    DevBuf<double> dL, dE, dI, dRho, dA, dWet, dCd, dFinAll, dNorms, dBlocks, dLv64;
+    DevBuf<double> dL, dE, dI, dRho, dA, dWet, dCd, dFinAll, dNorms, dBlocks, dLv64, dFd;
     DevBuf<uint8_t> dNl, dFree;
     DevBuf<GravTab> dGrav;
-    std::vector<GravTab> grav(S);
-    for (int j = 0; j < S; ++j) grav[j] = slots[j].grav;
-    const bool drag = d->flags & CRB_FORCE_DRAG;
-    // element columns, [nd][n_elem]
+    DevBuf<int32_t> dNe;
+    DevBuf<uint32_t> dFl;
+    const int nt = per_beam_topo ? nd : 1;   // beams whose integer topology is uploaded
+    std::vector<GravTab> grav(size_t(nt) * S);
+    std::vector<uint8_t> free_dof(size_t(nt) * nn * 3);
+    for (int b = 0; b < nt; ++b) {
+        std::memcpy(&grav[size_t(b) * S], topo[b]->grav.data(), size_t(S) * sizeof(GravTab));
+        std::memcpy(&free_dof[size_t(b) * nn * 3], topo[b]->free_dof.data(), size_t(nn) * 3);
+    }
+    (void)slots;
+    bool drag = false;
+    for (int b = 0; b < nd; ++b) drag = drag || (descs[b].flags & CRB_FORCE_DRAG);
+    // element columns, [nd][n_elem]; a beam shorter than the plan is padded (1.0: never read by an element)
     auto gather = [&](const double* crb_beam_desc::*col) {
-        std::vector<double> v(size_t(nd) * ne);
-        for (int b = 0; b < nd; ++b) std::memcpy(&v[size_t(b) * ne], descs[b].*col, size_t(ne) * sizeof(double));
+        std::vector<double> v(size_t(nd) * ne, 1.0);
+        for (int b = 0; b < nd; ++b)
+            if (descs[b].*col) std::memcpy(&v[size_t(b) * ne], descs[b].*col, size_t(descs[b].n_elem) * sizeof(double));
         return v;
     };
-    std::vector<uint8_t> nl(size_t(nd) * ne);
-    for (int b = 0; b < nd; ++b) std::memcpy(&nl[size_t(b) * ne], descs[b].nonlinear, size_t(ne));
+    std::vector<uint8_t> nl(size_t(nd) * ne, 0);
+    for (int b = 0; b < nd; ++b) std::memcpy(&nl[size_t(b) * ne], descs[b].nonlinear, size_t(descs[b].n_elem));
+    std::vector<int32_t> ne_b(nd);
+    std::vector<uint32_t> fl_b(nd);
+    std::vector<double> fd_b(nd);
+    for (int b = 0; b < nd; ++b) { ne_b[b] = descs[b].n_elem; fl_b[b] = descs[b].flags; fd_b[b] = descs[b].fluid_density; }
     const auto vL = gather(&crb_beam_desc::length), vE = gather(&crb_beam_desc::elastic_modulus),
                vI = gather(&crb_beam_desc::moment_inertia), vR = gather(&crb_beam_desc::density),
                vA = gather(&crb_beam_desc::cross_area);
@@ -137,7 +169,8 @@ int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::
     if (drag) { vW = gather(&crb_beam_desc::wetted_area); vC = gather(&crb_beam_desc::drag_coef); }
     if (dL.upload(vL.data(), vL.size()) || dE.upload(vE.data(), vE.size()) || dI.upload(vI.data(), vI.size()) ||
         dRho.upload(vR.data(), vR.size()) || dA.upload(vA.data(), vA.size()) || dNl.upload(nl.data(), nl.size()) ||
-        dFree.upload(free_dof.data(), free_dof.size()) || dGrav.upload(grav.data(), S) ||
+        dFree.upload(free_dof.data(), free_dof.size()) || dGrav.upload(grav.data(), grav.size()) ||
+        dNe.upload(ne_b.data(), nd) || dFl.upload(fl_b.data(), nd) || dFd.upload(fd_b.data(), nd) ||
         (drag && (dWet.upload(vW.data(), vW.size()) || dCd.upload(vC.data(), vC.size()))) ||
         dFinAll.alloc(size_t(lf + 1) * S * PCR_FINAL_VALS) || dNorms.alloc(lf) || dBlocks.alloc(size_t(S) * 15) ||
         dLv64.alloc(size_t(lf) * S * PCR_LEVEL_VALS))
@@ -145,8 +178,31 @@ int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::
     HIP_TRY(hipMalloc(&p->d_slot, size_t(nd) * S * sizeof(SlotConst<T>)));
     HIP_TRY(hipMalloc(&p->d_levels, size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
     HIP_TRY(hipMalloc(&p->d_final, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), p->free_index.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(p->d_free_index, p->free_index.data(), p->free_index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (p->mixed_topology) {   // per-beam reduced -> full maps, padded with -1 to the largest beam
+        std::vector<int32_t> fi(size_t(nd) * p->n_free, -1), nst(nd);
+        for (int b = 0; b < nd; ++b) {
+            std::memcpy(&fi[size_t(b) * p->n_free], topo[b]->free_index.data(), topo[b]->free_index.size() * sizeof(int32_t));
+            nst[b] = 2 * topo[b]->n_free;
+        }
+        p->free_index_stride = size_t(p->n_free);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), fi.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(p->d_free_index, fi.data(), fi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_n_state), nst.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(p->d_n_state, nst.data(), nst.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_free_index), p->free_index.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(p->d_free_index, p->free_index.data(), p->free_index.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    {   // per-beam gravity vectors (only when they differ)
+        bool differ = false;
+        for (int b = 1; b < nd; ++b) differ = differ || descs[b].gravity[0] != d->gravity[0] || descs[b].gravity[1] != d->gravity[1];
+        if (differ) {
+            std::vector<T> gv(size_t(nd) * 2);
+            for (int b = 0; b < nd; ++b) { gv[2 * b] = T(descs[b].gravity[0]); gv[2 * b + 1] = T(descs[b].gravity[1]); }
+            HIP_TRY(hipMalloc(&p->d_gvec, gv.size() * sizeof(T)));
+            HIP_TRY(hipMemcpy(p->d_gvec, gv.data(), gv.size() * sizeof(T), hipMemcpyHostToDevice));
+        }
+    }
     {   // offsets of the reduced ordering inside the device layouts (crb_feedback_force)
         const int n = p->n_free;
         std::vector<int32_t> col(size_t(2) * n), row(n);
@@ -173,6 +229,9 @@ int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::
     a.nonlinear = dNl.p; a.free_dof = dFree.p; a.wet = dWet.p; a.cd = dCd.p; a.grav = dGrav.p;
     a.fluid_density = d->fluid_density; a.flags = d->flags;
     a.n_elem = ne; a.n_node = p->n_node; a.off = p->off; a.S = S; a.levels_full = lf;
+    if (nd > 1) { a.n_elem_b = dNe.p; a.fluid_density_b = dFd.p; a.flags_b = dFl.p; }
+    a.free_stride = per_beam_topo ? size_t(nn) * 3 : 0;
+    a.grav_stride = per_beam_topo ? size_t(S) : 0;
     a.slot_out = p->d_slot; a.lv64 = dLv64.p; a.lvT = p->d_levels; a.fin64_all = dFinAll.p; a.norms = dNorms.p;
     a.blocks0 = dBlocks.p; a.finT = nullptr; a.fin_level = -1;
     a.elem_stride = nd > 1 ? size_t(ne) : 0;
@@ -243,57 +302,119 @@ extern "C" int crb_plan_create_ensemble(crb_plan** out, int device, int dtype, i
     if (n_beams < 1) return fail(CRB_EINVAL, "n_beams must be >= 1");
     if (device < 0) return fail(CRB_EUNSUPPORTED, "per-beam coefficient plans are built on the device (no host-only form)");
     const crb_beam_desc& a = descs[0];
-    for (int b = 1; b < n_beams; ++b) {
-        const crb_beam_desc& d = descs[b];
-        if (d.n_elem != a.n_elem || d.flags != a.flags || d.fluid_density != a.fluid_density ||
-            d.gravity[0] != a.gravity[0] || d.gravity[1] != a.gravity[1] || !d.node_bc || !a.node_bc ||
-            std::memcmp(d.node_bc, a.node_bc, size_t(a.n_elem) + 1) != 0)
-            return fail(CRB_EINVAL, "ensemble beams must share n_elem, boundary conditions and force parameters");
-    }
+    for (int b = 1; b < n_beams; ++b)   // the one thing an ensemble must share: the element variant compiled into the kernels
+        if ((descs[b].flags & CRB_CORRECTED_AXIAL) != (a.flags & CRB_CORRECTED_AXIAL))
+            return fail(CRB_EINVAL, "ensemble beams must share the CRB_CORRECTED_AXIAL option");
     return plan_create_impl(out, device, dtype, n_beams, descs, n_beams);
 }
+
+namespace {
+// CSV-row validation of one beam: Properties.__post_init__ / EulerBernoulliBeam._validate_parameters
+// (abstractions.py:39-53, euler_bernoulli_beam.py:100-103), ForceParams / FluidDragForce (force_params.py:41-43,
+// fluid_forces.py:59-72).  Returns nullptr or the reference's message.
+const char* validate_desc(const crb_beam_desc& o) {
+    if (o.n_elem < 1) return "n_elem must be >= 1";
+    if (!o.length || !o.elastic_modulus || !o.moment_inertia || !o.density || !o.cross_area || !o.nonlinear || !o.node_bc)
+        return "beam description has null columns";
+    for (int e = 0; e < o.n_elem; ++e) {
+        if (!(o.length[e] > 0) || !(o.elastic_modulus[e] > 0) || !(o.moment_inertia[e] > 0) || !(o.density[e] > 0) ||
+            !(o.cross_area[e] > 0))
+            return "All numeric parameters must be positive";
+        if (o.nonlinear[e] > 1) return "Invalid element type";
+    }
+    for (int i = 0; i <= o.n_elem; ++i)
+        if (o.node_bc[i] != CRB_BC_NONE && o.node_bc[i] != CRB_BC_FIXED && o.node_bc[i] != CRB_BC_PINNED)
+            return "Unsupported boundary condition type";
+    if (o.flags & CRB_FORCE_DRAG) {
+        if (!o.wetted_area || !o.drag_coef) return "drag enabled but wetted_area/drag_coef missing";
+        if (!(o.fluid_density > 0)) return "fluid_density must be positive when fluid effects are enabled";
+        for (int e = 0; e < o.n_elem; ++e) {
+            if (o.drag_coef[e] < 0) return "Drag coefficients cannot be negative";
+            if (o.wetted_area[e] < 0) return "Wetted areas cannot be negative";
+        }
+    }
+    return nullptr;
+}
+
+// Integer topology of a beam of d.n_elem elements inside a plan of nn nodes whose first `off` nodes carry no slot:
+// boundary conditions -> free masks and the reduced ordering (euler_bernoulli_beam.py:240-259); the gravity index
+// table with the reference's reduced-index addressing (gravity_forces.py:97-146).
+BeamTopo build_topology(const crb_beam_desc& d, int nn, int off) {
+    BeamTopo t;
+    const int ne = d.n_elem, S = nn - off;
+    t.n_elem = ne;
+    t.free_dof.assign(size_t(nn) * 3, 0);    // nodes past the beam's own last node (index ne) stay fully constrained
+    for (int i = 0; i <= ne; ++i) {
+        const int bc = d.node_bc[i];
+        const bool fx = bc == CRB_BC_FIXED, pin = bc == CRB_BC_PINNED;
+        t.free_dof[3 * i] = t.free_dof[3 * i + 1] = (fx || pin) ? 0 : 1;
+        t.free_dof[3 * i + 2] = fx ? 0 : 1;
+    }
+    t.full2red.assign(size_t(nn) * 3, -1);
+    for (int f = 0; f < 3 * nn; ++f)
+        if (t.free_dof[f]) { t.full2red[f] = int32_t(t.free_index.size()); t.free_index.push_back(f); }
+    t.n_free = int(t.free_index.size());
+    const int n = t.n_free;
+    t.grav.resize(S);
+    const bool grav = d.flags & CRB_FORCE_GRAVITY;
+    for (int j = 0; j < S; ++j) {
+        GravTab& gt = t.grav[j];
+        gt.phiA = gt.phiB = -1;
+        for (int c = 0; c < 3; ++c) { gt.segA[c] = gt.segB[c] = -1; gt.comp[c] = 0; }
+        gt.pad = 0;
+        if (!grav) continue;
+        const int node = j + off;
+        auto enc = [&](int red) -> int16_t {
+            const int f = t.free_index[red];
+            return int16_t(((f / 3) - off) * 4 + (f % 3));
+        };
+        if (j < ne) {  // this thread evaluates segment j (gravity_forces.py:97-128)
+            const int sp = 3 * j + 2, ep = 3 * (j + 1) + 2;  // indices into the REDUCED vector
+            if (sp < n) gt.phiA = enc(sp);
+            if (ep < n) gt.phiB = enc(ep);
+        }
+        for (int c = 0; c < 3; ++c) {  // which segments add to this DOF (gravity_forces.py:130-146)
+            const int r = t.full2red[3 * node + c];
+            if (r < 0 || r % 3 == 2) continue;
+            gt.comp[c] = int8_t(r % 3);
+            if (r / 3 < ne) gt.segA[c] = int16_t(r / 3);
+            if (r / 3 - 1 >= 0) gt.segB[c] = int16_t(r / 3 - 1);
+        }
+    }
+    // does the gravity table reduce to "segment j <-> slots j, j+1" (the plain cantilever filling the whole plan)?
+    t.canonical_gravity = false;
+    if (grav && off == 1 && ne == S) {
+        bool canon = true;
+        for (int j = 0; j < S && canon; ++j) {
+            const GravTab& gt = t.grav[j];
+            canon = gt.phiA == int16_t(j * 4 + 2) && gt.phiB == (j + 1 < S ? int16_t((j + 1) * 4 + 2) : int16_t(-1)) &&
+                    gt.segA[2] < 0 && gt.segB[2] < 0;
+            for (int c = 0; c < 2 && canon; ++c)
+                canon = gt.comp[c] == c && gt.segA[c] == int16_t(j) && gt.segB[c] == int16_t(j - 1 >= 0 ? j - 1 : -1);
+        }
+        t.canonical_gravity = canon;
+    }
+    return t;
+}
+}  // namespace
 
 static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* d, int nd) {
     if (!out || !d) return fail(CRB_EINVAL, "crb_plan_create: null argument");
     *out = nullptr;
     if (dtype != CRB_F64 && dtype != CRB_F32) return fail(CRB_EINVAL, "dtype must be CRB_F64 or CRB_F32");
     if (n_beams < 1) return fail(CRB_EINVAL, "n_beams must be >= 1");
-    const int ne = d->n_elem;
-    if (ne < 1) return fail(CRB_EINVAL, "n_elem must be >= 1");
-    for (int b = 1; b < nd; ++b) {  // the other beams of a per-beam-coefficient ensemble
-        const crb_beam_desc& o = d[b];
-        if (!o.length || !o.elastic_modulus || !o.moment_inertia || !o.density || !o.cross_area || !o.nonlinear)
-            return fail(CRB_EINVAL, "beam description has null columns");
-        for (int e = 0; e < ne; ++e) {
-            if (!(o.length[e] > 0) || !(o.elastic_modulus[e] > 0) || !(o.moment_inertia[e] > 0) || !(o.density[e] > 0) ||
-                !(o.cross_area[e] > 0))
-                return fail(CRB_EINVAL, "All numeric parameters must be positive");
-            if (o.nonlinear[e] > 1) return fail(CRB_EINVAL, "Invalid element type");
-            if ((o.flags & CRB_FORCE_DRAG) && (!o.wetted_area || !o.drag_coef || o.drag_coef[e] < 0 || o.wetted_area[e] < 0))
-                return fail(CRB_EINVAL, "Drag coefficients / wetted areas missing or negative");
-        }
+    for (int b = 0; b < nd; ++b)
+        if (const char* msg = validate_desc(d[b])) return fail(CRB_EINVAL, msg);
+    // the plan's node count is the longest beam's; shorter beams end in padding nodes (fully constrained, no element)
+    int ne = 0;
+    bool all_fixed_root = true, any_drag = false, any_grav = false;
+    for (int b = 0; b < nd; ++b) {
+        ne = d[b].n_elem > ne ? d[b].n_elem : ne;
+        all_fixed_root = all_fixed_root && d[b].node_bc[0] == CRB_BC_FIXED;
+        any_drag = any_drag || (d[b].flags & CRB_FORCE_DRAG);
+        any_grav = any_grav || (d[b].flags & CRB_FORCE_GRAVITY);
     }
-    if (!d->length || !d->elastic_modulus || !d->moment_inertia || !d->density || !d->cross_area || !d->nonlinear ||
-        !d->node_bc)
-        return fail(CRB_EINVAL, "beam description has null columns");
-    for (int e = 0; e < ne; ++e) {
-        // Properties.__post_init__ / EulerBernoulliBeam._validate_parameters (abstractions.py:39-53,
-        // euler_bernoulli_beam.py:100-103)
-        if (!(d->length[e] > 0) || !(d->elastic_modulus[e] > 0) || !(d->moment_inertia[e] > 0) ||
-            !(d->density[e] > 0) || !(d->cross_area[e] > 0))
-            return fail(CRB_EINVAL, "All numeric parameters must be positive");
-        if (d->nonlinear[e] > 1) return fail(CRB_EINVAL, "Invalid element type");
-    }
-    const bool drag = d->flags & CRB_FORCE_DRAG, grav = d->flags & CRB_FORCE_GRAVITY;
-    if (drag) {
-        if (!d->wetted_area || !d->drag_coef) return fail(CRB_EINVAL, "drag enabled but wetted_area/drag_coef missing");
-        if (!(d->fluid_density > 0))
-            return fail(CRB_EINVAL, "fluid_density must be positive when fluid effects are enabled");
-        for (int e = 0; e < ne; ++e) {
-            if (d->drag_coef[e] < 0) return fail(CRB_EINVAL, "Drag coefficients cannot be negative");
-            if (d->wetted_area[e] < 0) return fail(CRB_EINVAL, "Wetted areas cannot be negative");
-        }
-    }
+    const bool grav = any_grav;
 
     crb_plan* p = new crb_plan();
     p->device = device;
@@ -301,29 +422,52 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
     p->B = n_beams;
     p->n_elem = ne;
     p->n_node = ne + 1;
-    p->flags = d->flags;
+    // force terms compiled into a launch = the union over the beams; a beam without drag / gravity has zero drag
+    // factors / zero segment masses in its slot table
+    p->flags = (d->flags & CRB_CORRECTED_AXIAL) | (any_drag ? CRB_FORCE_DRAG : 0u) | (any_grav ? CRB_FORCE_GRAVITY : 0u);
     p->gx = d->gravity[0];
     p->gy = d->gravity[1];
-
-    // boundary conditions -> free masks (euler_bernoulli_beam.py:240-259)
     const int nn = p->n_node;
-    std::vector<uint8_t> free_dof(size_t(nn) * 3, 1);
-    for (int i = 0; i < nn; ++i) {
-        const int bc = d->node_bc[i];
-        if (bc == CRB_BC_FIXED) free_dof[3 * i] = free_dof[3 * i + 1] = free_dof[3 * i + 2] = 0;
-        else if (bc == CRB_BC_PINNED) free_dof[3 * i] = free_dof[3 * i + 1] = 0;
-        else if (bc != CRB_BC_NONE) { delete p; return fail(CRB_EINVAL, "Unsupported boundary condition type"); }
-    }
-    p->full2red.assign(size_t(nn) * 3, -1);
-    for (int f = 0; f < 3 * nn; ++f)
-        if (free_dof[f]) { p->full2red[f] = int32_t(p->free_index.size()); p->free_index.push_back(f); }
-    p->n_free = int(p->free_index.size());
-    if (p->n_free == 0) { delete p; return fail(CRB_EINVAL, "Cannot constrain all degrees of freedom"); }
-
-    p->off = (d->node_bc[0] == CRB_BC_FIXED) ? 1 : 0;
+    // node 0 carries no thread slot when it is FIXED in every beam (the cantilever of the examples)
+    p->off = all_fixed_root ? 1 : 0;
     p->S = nn - p->off;
     const int S = p->S;
     if (S > 1024) { delete p; return fail(CRB_EUNSUPPORTED, "more than 1024 thread-carried nodes per beam"); }
+
+    // ---- integer topology per DISTINCT (n_elem, boundary conditions, gravity on/off) among the beams
+    std::vector<BeamTopo> topos;
+    std::vector<int> topo_of(nd, 0);
+    for (int b = 0; b < nd; ++b) {
+        int hit = -1;
+        for (int c = 0; c < b && hit < 0; ++c)
+            if (d[c].n_elem == d[b].n_elem && std::memcmp(d[c].node_bc, d[b].node_bc, size_t(d[b].n_elem) + 1) == 0 &&
+                ((d[c].flags ^ d[b].flags) & CRB_FORCE_GRAVITY) == 0)
+                hit = topo_of[c];
+        if (hit < 0) { topos.push_back(build_topology(d[b], nn, p->off)); hit = int(topos.size()) - 1; }
+        topo_of[b] = hit;
+    }
+    std::vector<const BeamTopo*> topo(nd);
+    for (int b = 0; b < nd; ++b) topo[b] = &topos[topo_of[b]];
+    const BeamTopo& t0 = *topo[0];
+    p->free_index = t0.free_index;
+    p->full2red = t0.full2red;
+    p->n_free = t0.n_free;
+    p->any_free = t0.free_dof;
+    bool per_beam_topo = topos.size() > 1;
+    for (int b = 1; b < nd; ++b) {
+        if (topo[b]->free_dof != t0.free_dof) p->mixed_topology = true;
+        if (topo[b]->n_free > p->n_free) p->n_free = topo[b]->n_free;
+        for (size_t f = 0; f < p->any_free.size(); ++f) p->any_free[f] = p->any_free[f] | topo[b]->free_dof[f];
+    }
+    if (p->mixed_topology) {
+        p->beam_n_elem.resize(nd); p->beam_n_free.resize(nd); p->beam_free_index.resize(nd);
+        for (int b = 0; b < nd; ++b) {
+            p->beam_n_elem[b] = topo[b]->n_elem; p->beam_n_free[b] = topo[b]->n_free; p->beam_free_index[b] = topo[b]->free_index;
+        }
+    }
+    for (int b = 0; b < nd; ++b)
+        if (topo[b]->n_free == 0) { delete p; return fail(CRB_EINVAL, "Cannot constrain all degrees of freedom"); }
+
     // S >= 64: one beam per workgroup of NW = 2^lognw wavefronts (slots interleaved over the waves);
     // S < 64: G = 64/S whole beams per single-wave workgroup
     p->lognw = 0;
@@ -339,71 +483,46 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
     while ((1 << lf) < S) ++lf;
     p->levels_full = lf;
 
-    // ---- per-slot constants
+    // ---- per-slot constants of beam 0 (host copies for the inspectors; the device tables come from crb_assemble_kernel)
     std::vector<SlotConst<double>> slots(S);
     std::vector<int> kinds(S, KIND_NONE);
-    const int n = p->n_free;
+    const bool drag = d->flags & CRB_FORCE_DRAG;
     for (int j = 0; j < S; ++j) {
         SlotConst<double>& s = slots[j];
         std::memset(&s, 0, sizeof(s));
         const int node = j + p->off;
         const int e = node - 1;
-        if (e >= 0) kinds[j] = d->nonlinear[e] ? KIND_NONLINEAR : KIND_LINEAR;
-        for (int c = 0; c < 3; ++c) s.mask[c] = free_dof[3 * node + c] ? 1.0 : 0.0;
-        if (drag && free_dof[3 * node + 1]) {
+        if (e >= 0 && e < d->n_elem) kinds[j] = d->nonlinear[e] ? KIND_NONLINEAR : KIND_LINEAR;
+        for (int c = 0; c < 3; ++c) s.mask[c] = t0.free_dof[3 * node + c] ? 1.0 : 0.0;
+        if (drag && t0.free_dof[3 * node + 1]) {
             // fluid_forces.py:59-61, 87-90: the node's own segment row, last row repeated for the tip
-            const int row = node < ne ? node : ne - 1;
+            const int row = node < d->n_elem ? node : d->n_elem - 1;
             s.drag = 0.5 * d->fluid_density * d->drag_coef[row] * d->wetted_area[row];
         }
-        GravTab& gt = s.grav;
-        gt.phiA = gt.phiB = -1;
-        for (int c = 0; c < 3; ++c) { gt.segA[c] = gt.segB[c] = -1; gt.comp[c] = 0; }
-        gt.pad = 0;
-        if (grav) {
-            auto enc = [&](int red) -> int16_t {
-                const int f = p->free_index[red];
-                return int16_t(((f / 3) - p->off) * 4 + (f % 3));
-            };
-            if (j < ne) {  // this thread evaluates segment j (gravity_forces.py:97-128)
-                s.half_mass = 0.5 * (d->density[j] * d->cross_area[j] * d->length[j]);
-                const int sp = 3 * j + 2, ep = 3 * (j + 1) + 2;  // indices into the REDUCED vector
-                if (sp < n) gt.phiA = enc(sp);
-                if (ep < n) gt.phiB = enc(ep);
-            }
-            for (int c = 0; c < 3; ++c) {  // which segments add to this DOF (gravity_forces.py:130-146)
-                const int r = p->full2red[3 * node + c];
-                if (r < 0 || r % 3 == 2) continue;
-                gt.comp[c] = int8_t(r % 3);
-                if (r / 3 < ne) gt.segA[c] = int16_t(r / 3);
-                if (r / 3 - 1 >= 0) gt.segB[c] = int16_t(r / 3 - 1);
-            }
-        }
+        s.grav = t0.grav[j];
+        if ((d->flags & CRB_FORCE_GRAVITY) && j < d->n_elem) s.half_mass = 0.5 * (d->density[j] * d->cross_area[j] * d->length[j]);
     }
-
     p->h_slots = slots;
     p->h_kinds = kinds;
-    {   // one element kind over the whole topology?
+    {   // one element kind over the whole ensemble?
         bool all_nl = true, all_lin = true;
-        for (int b = 0; b < nd; ++b)   // every beam of a per-beam-coefficient ensemble
-            for (int e = 0; e < ne; ++e) { all_nl = all_nl && d[b].nonlinear[e]; all_lin = all_lin && !d[b].nonlinear[e]; }
+        for (int b = 0; b < nd; ++b)
+            for (int e = 0; e < d[b].n_elem; ++e) { all_nl = all_nl && d[b].nonlinear[e]; all_lin = all_lin && !d[b].nonlinear[e]; }
         p->elem_mode = all_lin ? EM_LINEAR : (all_nl && !(d->flags & CRB_CORRECTED_AXIAL)) ? EM_NONLINEAR : EM_MIXED;
         if (std::getenv("CRB_DISABLE_ELEM_MODE")) p->elem_mode = EM_MIXED;
     }
-    if (grav && p->off == 1 && ne == S) {  // does the gravity table reduce to "segment j <-> slots j, j+1"?
+    if (grav) {   // nearest-neighbour gravity (lean kernels) only if EVERY beam that has gravity is the canonical cantilever
         bool canon = true;
-        for (int j = 0; j < S && canon; ++j) {
-            const GravTab& gt = slots[j].grav;
-            canon = gt.phiA == int16_t(j * 4 + 2) && gt.phiB == (j + 1 < S ? int16_t((j + 1) * 4 + 2) : int16_t(-1)) &&
-                    gt.segA[2] < 0 && gt.segB[2] < 0;
-            for (int c = 0; c < 2 && canon; ++c)
-                canon = gt.comp[c] == c && gt.segA[c] == int16_t(j) && gt.segB[c] == int16_t(j - 1 >= 0 ? j - 1 : -1);
-        }
+        for (int b = 0; b < nd; ++b)
+            if (d[b].flags & CRB_FORCE_GRAVITY) canon = canon && topo[b]->canonical_gravity;
+            else canon = canon && d[b].n_elem == S && p->off == 1;   // (a gravity-free beam only needs the same slot layout)
         p->canonical_gravity = canon;
     }
 
-    {   // dense reduced stiffness of the linear elements (get_stiffness_matrix); columns = K_e * unit vectors
+    const int n = t0.n_free;
+    {   // dense reduced stiffness of beam 0's linear elements (get_stiffness_matrix); columns = K_e * unit vectors
         p->h_stiff.assign(size_t(n) * n, 0.0);
-        for (int e = 0; e < ne; ++e) {
+        for (int e = 0; e < d->n_elem; ++e) {
             if (d->nonlinear[e]) { if (p->first_nonlinear < 0) p->first_nonlinear = e; continue; }
             ElemCoef<double> ec;
             elem_coef_build<double>(ec, KIND_LINEAR, d->length[e], d->elastic_modulus[e], d->moment_inertia[e],
@@ -422,7 +541,8 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
         }
     }
     if (device < 0) {
-    // ======== host-only plan (inspection): same arithmetic (crb_math.h) in plain C++ ========
+    // ======== host-only plan (inspection, one shared beam): same arithmetic (crb_math.h) in plain C++ ========
+    const std::vector<uint8_t>& free_dof = t0.free_dof;
     // ---- mass matrix in node-block form + cyclic-reduction factorisation (all fp64)
     std::vector<NodeBlocks> cur(S), nxt(S);
     auto fm = [&](int node, int c) { return node >= 0 && node < nn && free_dof[3 * node + c] != 0; };
@@ -498,8 +618,8 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete p; return fail(CRB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
         // ======== device plan: crb_assemble_kernel builds every floating-point table ========
-        const int rc = (dtype == CRB_F64) ? device_assemble<double>(p, d, nd, slots, free_dof)
-                                          : device_assemble<float>(p, d, nd, slots, free_dof);
+        const int rc = (dtype == CRB_F64) ? device_assemble<double>(p, d, nd, slots, topo, per_beam_topo)
+                                          : device_assemble<float>(p, d, nd, slots, topo, per_beam_topo);
         if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
         if (rc != CRB_OK) { crb_plan_destroy(p); return rc; }
     }
@@ -521,6 +641,8 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         (void)hipFree(p->d_free_index);
         (void)hipFree(p->d_col_off);
         (void)hipFree(p->d_row_off);
+        (void)hipFree(p->d_gvec);
+        (void)hipFree(p->d_n_state);
     }
     delete p;
 }
@@ -538,13 +660,29 @@ extern "C" int crb_plan_get_layout(const crb_plan* p, crb_layout* o) {
     o->threads = p->NT;
     o->pcr_levels = p->levels;
     o->pcr_levels_full = p->levels_full;
-    o->reserved = 0;
+    o->mixed_topology = p->mixed_topology ? 1 : 0;
     return CRB_OK;
 }
 
 extern "C" int crb_plan_get_free_index(const crb_plan* p, int32_t* out) {
     if (!p || !out) return fail(CRB_EINVAL, "null argument");
     std::memcpy(out, p->free_index.data(), p->free_index.size() * sizeof(int32_t));
+    return CRB_OK;
+}
+
+extern "C" int crb_plan_get_beam_info(const crb_plan* p, int beam, int32_t* n_elem, int32_t* n_free) {
+    if (!p) return fail(CRB_EINVAL, "null argument");
+    if (beam < 0 || beam >= p->B) return fail(CRB_EINVAL, "crb_plan_get_beam_info: beam out of range");
+    if (n_elem) *n_elem = p->mixed_topology ? p->beam_n_elem[beam] : p->n_elem;
+    if (n_free) *n_free = p->mixed_topology ? p->beam_n_free[beam] : int32_t(p->free_index.size());
+    return CRB_OK;
+}
+
+extern "C" int crb_plan_get_beam_free_index(const crb_plan* p, int beam, int32_t* out) {
+    if (!p || !out) return fail(CRB_EINVAL, "null argument");
+    if (beam < 0 || beam >= p->B) return fail(CRB_EINVAL, "crb_plan_get_beam_free_index: beam out of range");
+    const std::vector<int32_t>& fi = p->mixed_topology ? p->beam_free_index[beam] : p->free_index;
+    std::memcpy(out, fi.data(), fi.size() * sizeof(int32_t));
     return CRB_OK;
 }
 
@@ -623,9 +761,11 @@ KParams<T> base_params(const crb_plan* p) {
     k.flags = p->flags;
     k.imp_slot = -1;
     k.imp_dof = 0;
+    k.imp_node_b = nullptr;
     k.duration = 0.0;
     k.gx = T(p->gx);
     k.gy = T(p->gy);
+    k.gvec = static_cast<const T*>(p->d_gvec);
     return k;
 }
 
@@ -738,10 +878,10 @@ int pack_impl(const crb_plan* p, bool pack, int rows, const void* red_in, void* 
     const unsigned grid = unsigned((total + bs - 1) / bs);
     if (pack) {
         HIP_TRY(hipMemsetAsync(dev, 0, size_t(p->B) * rows * p->n_node * 4 * sizeof(T), st));
-        hipLaunchKernelGGL((crb_pack_kernel<T, true>), dim3(grid), dim3(bs), 0, st, p->d_free_index, p->n_free, p->n_node,
+        hipLaunchKernelGGL((crb_pack_kernel<T, true>), dim3(grid), dim3(bs), 0, st, p->d_free_index, p->free_index_stride, p->n_free, p->n_node,
                            rows, p->B, static_cast<const T*>(red_in), static_cast<T*>(dev), static_cast<T*>(nullptr));
     } else {
-        hipLaunchKernelGGL((crb_pack_kernel<T, false>), dim3(grid), dim3(bs), 0, st, p->d_free_index, p->n_free, p->n_node,
+        hipLaunchKernelGGL((crb_pack_kernel<T, false>), dim3(grid), dim3(bs), 0, st, p->d_free_index, p->free_index_stride, p->n_free, p->n_node,
                            rows, p->B, static_cast<const T*>(nullptr), static_cast<T*>(dev), static_cast<T*>(red_out));
     }
     HIP_TRY(hipGetLastError());
@@ -843,7 +983,7 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
             if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2)
                 return fail(CRB_EINVAL, "crb_step_rk4: impulse node/dof out of range");
             if (!in->amp) return fail(CRB_EINVAL, "crb_step_rk4: impulse amplitude array is null");
-            if (p->full2red[3 * in->node + in->dof] < 0)
+            if (!p->any_free[3 * in->node + in->dof])   // (mixed ensembles: a beam in which the DOF is constrained ignores it)
                 return fail(CRB_EINVAL, "crb_step_rk4: impulse targets a constrained DOF");
             imp_slot = in->node - p->off;
             imp_dof = in->dof;
@@ -867,6 +1007,7 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
         k.u_held = static_cast<const double*>(held);
         k.amp = static_cast<const double*>(amp);
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+        k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
         k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
         k.rec_out = static_cast<double*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
         if (lean_eligible(p, held)) return launch_lean<double>(p, k, st);
@@ -877,6 +1018,7 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     k.u_held = static_cast<const float*>(held);
     k.amp = static_cast<const float*>(amp);
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+    k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
     k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
     k.rec_out = static_cast<float*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
     if (lean_eligible(p, held)) return launch_lean<float>(p, k, st);
@@ -961,7 +1103,8 @@ extern "C" int crb_step_rk4_feedback(const crb_plan* p, void* x, double t0, doub
         uint64_t dur;
         std::memcpy(&dur, &in->duration, sizeof(dur));
         key.insert(key.end(), {uint64_t(in->kind), uint64_t(in->node), uint64_t(in->dof), dur,
-                               uint64_t(reinterpret_cast<uintptr_t>(in->amp)), uint64_t(reinterpret_cast<uintptr_t>(in->f_held))});
+                               uint64_t(reinterpret_cast<uintptr_t>(in->amp)), uint64_t(reinterpret_cast<uintptr_t>(in->f_held)),
+                               uint64_t(reinterpret_cast<uintptr_t>(in->node_b))});
     }
     const char* tile = std::getenv("CRB_FEEDBACK_TILE");
     key.push_back(tile ? uint64_t(std::atoi(tile)) : 0);
@@ -1066,7 +1209,7 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
         held = in->f_held;
         if (in->kind == CRB_INPUT_IMPULSE) {
             if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp ||
-                p->full2red[3 * in->node + in->dof] < 0)
+                !p->any_free[3 * in->node + in->dof])
                 return fail(CRB_EINVAL, "crb_solve_rk45: bad impulse description");
             imp_slot = in->node - p->off; imp_dof = in->dof; duration = in->duration; amp = in->amp;
         }
@@ -1074,7 +1217,7 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
     Rk45Params q;
     q.t0 = t0; q.t_end = t_end; q.rtol = rtol; q.atol = atol;
     q.h_io = static_cast<double*>(h); q.stats = static_cast<int32_t*>(stats);
-    q.n_state = 2 * p->n_free; q.max_steps = max_steps > 0 ? max_steps : 100000000;
+    q.n_state = 2 * p->n_free; q.n_state_b = p->d_n_state; q.max_steps = max_steps > 0 ? max_steps : 100000000;
     q.eval_out = nullptr; q.eval_t0 = eval_t0; q.eval_dt = eval_dt; q.n_eval = 0; q.eval_slot = -1; q.eval_comp = 0;
     if (rec && n_eval > 0 && eval_all) {
         q.eval_out = rec->out; q.n_eval = n_eval; q.eval_slot = REC_ALL_SLOTS;
@@ -1086,11 +1229,13 @@ extern "C" int crb_solve_rk45_eval(const crb_plan* p, void* x, double t0, double
         KParams<double> k = base_params<double>(p);
         k.x = static_cast<double*>(x); k.u_held = static_cast<const double*>(held); k.amp = static_cast<const double*>(amp);
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+        k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
         return launch_rk45<double>(p, k, q, st);
     }
     KParams<float> k = base_params<float>(p);
     k.x = static_cast<float*>(x); k.u_held = static_cast<const float*>(held); k.amp = static_cast<const float*>(amp);
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+    k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
     return launch_rk45<float>(p, k, q, st);
 }
 
@@ -1155,6 +1300,8 @@ int feedback_force_impl(const crb_plan* p, const void* xs, const void* gain, con
 extern "C" int crb_feedback_force(const crb_plan* p, const void* xs, const void* gain, const void* ref, void* u, void* stream) {
     if (int rc = need_device(p, "crb_feedback_force")) return rc;
     if (!xs || !gain || !u) return fail(CRB_EINVAL, "crb_feedback_force: null pointer");
+    if (p->mixed_topology)
+        return fail(CRB_EUNSUPPORTED, "crb_feedback_force: one gain matrix for the ensemble needs one free-DOF set (uniform boundary conditions / lengths)");
     return p->dtype == CRB_F64 ? feedback_force_impl<double>(p, xs, gain, ref, u, stream)
                                : feedback_force_impl<float>(p, xs, gain, ref, u, stream);
 }
@@ -1177,7 +1324,7 @@ static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc,
     const void* amp = nullptr;
     if (in && in->kind == CRB_INPUT_IMPULSE) {
         if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp ||
-            p->full2red[3 * in->node + in->dof] < 0)
+            !p->any_free[3 * in->node + in->dof])
             return fail(CRB_EINVAL, "crb_rk4_stage: bad impulse description");
         imp_slot = in->node - p->off; imp_dof = in->dof; duration = in->duration; amp = in->amp;
     }
@@ -1188,6 +1335,7 @@ static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc,
         k.out = static_cast<double*>(xs_next); k.u_held = static_cast<const double*>(u_stage);
         k.amp = static_cast<const double*>(amp);
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+        k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
         k.stage = stage; k.t0 = t_stage; k.dt = dt; k.t_dev = t_dev;
         if (stage_lean_eligible(p)) return launch_stage_lean<double>(p, k, st);
         return launch_beam<double, MODE_STAGE>(p, k, st);
@@ -1197,6 +1345,7 @@ static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc,
     k.out = static_cast<float*>(xs_next); k.u_held = static_cast<const float*>(u_stage);
     k.amp = static_cast<const float*>(amp);
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+    k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
     k.stage = stage; k.t0 = t_stage; k.dt = dt; k.t_dev = t_dev;
     if (stage_lean_eligible(p)) return launch_stage_lean<float>(p, k, st);
     return launch_beam<float, MODE_STAGE>(p, k, st);

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRB_VERSION 100
+#define CRB_VERSION 101
 
 enum { CRB_OK = 0, CRB_EINVAL = -1, CRB_EHIP = -2, CRB_ENODEV = -3, CRB_EUNSUPPORTED = -4 };
 enum { CRB_F64 = 0, CRB_F32 = 1 };
@@ -76,7 +76,9 @@ typedef struct crb_layout {
     int32_t threads;      /* workgroup size */
     int32_t pcr_levels;   /* cyclic-reduction levels the mass solve applies */
     int32_t pcr_levels_full; /* ceil(log2(n_slots)): levels of the untruncated reduction */
-    int32_t reserved;
+    int32_t mixed_topology; /* 1: the beams' free-DOF sets differ (per-beam n_elem / boundary conditions): n_elem and
+                             * n_free are the ensemble's maxima, reduced vectors are padded to n_free per beam
+                             * (crb_plan_get_beam_info / crb_plan_get_beam_free_index give each beam's own) */
 } crb_layout;
 
 /* External generalised force u(t) added to the right-hand side, the `u` of
@@ -93,6 +95,8 @@ typedef struct crb_input_desc {
     double duration;     /* impulse: seconds */
     const void* amp;     /* impulse: device [B], plan dtype */
     const void* f_held;  /* device [B][n_node][4] or NULL */
+    const int32_t* node_b; /* impulse: device [B] per-beam node (overrides `node`), or NULL -- beams of different length
+                            * each forced at their own tip (`u[-2]` of example_utilities.py:147 per beam) */
 } crb_input_desc;
 
 /* Strided on-device recording of one DOF during crb_step_rk4_rec: the `t_eval` output of the
@@ -122,11 +126,22 @@ const char* crb_last_error(void);
  * device >= 0: HIP device ordinal, tables are uploaded.  device == -1: host-only plan for
  * inspection (crb_plan_get_* work, every launch returns CRB_ENODEV). */
 int crb_plan_create(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* desc);
-/* Per-beam coefficients (heterogeneous ensembles, SURVEY f-3): descs[n_beams], one CSV-schema record
- * per beam.  All beams must share n_elem, node_bc, flags, fluid_density and gravity; every element
- * column (and the linear/nonlinear type) may differ per beam.  Assembly and factorisation run
- * batched on the device (one workgroup per beam); the inspectors (crb_plan_get_*) describe beam 0. */
+/* Heterogeneous ensembles (SURVEY f-3): descs[n_beams], one CSV-schema record + ForceParams per beam -- what the
+ * reference's parallel examples run as independent simulations (examples/beam_comparison_fluid.py:49-83: six beams,
+ * three without and three with fluid; beam_comparison_gravity.py:53-66).  Per beam: every element column and the
+ * linear/nonlinear type; n_elem (the plan is laid out for the longest beam, a shorter one ends in padding nodes that
+ * are fully constrained and carry no element); node_bc (dynamic_beam_model.py:205-218, euler_bernoulli_beam.py:221-298);
+ * fluid_density, the gravity vector and the DRAG / GRAVITY flags (dynamic_beam_model.py:220-241).  Only
+ * CRB_CORRECTED_AXIAL must be common.  Assembly and factorisation run batched on the device (one workgroup per beam).
+ * When the beams' free-DOF sets differ (crb_layout.mixed_topology) the reduced vectors of crb_pack_* / crb_unpack_*
+ * are [B][rows][n_free] with n_free the ensemble's maximum: beam b uses the first n_free_b entries of each row, the
+ * rest is ignored on pack and zero on unpack; crb_feedback_force (one gain for the whole ensemble) is not available.
+ * The host inspectors (crb_plan_get_free_index/_mass/_stiffness/_pcr_tables/_slot_tables) describe beam 0. */
 int crb_plan_create_ensemble(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* descs);
+/* n_elem and n_free (size of the reference's reduced position vector) of one beam of the plan; either may be NULL */
+int crb_plan_get_beam_info(const crb_plan* plan, int beam, int32_t* n_elem, int32_t* n_free);
+/* reduced index -> full index 3*node+dof of one beam, [n_free of that beam] host */
+int crb_plan_get_beam_free_index(const crb_plan* plan, int beam, int32_t* full_index);
 void crb_plan_destroy(crb_plan* plan);
 int crb_plan_get_layout(const crb_plan* plan, crb_layout* out);
 /* reduced index -> full index 3*node+dof, ascending (euler_bernoulli_beam.py:258-259); [n_free] host */
