@@ -45,6 +45,55 @@ def _columns(parameters, need_fluid):
     return cols
 
 
+class _FusedForce:
+    """Marker for a built-in force that the RHS kernel evaluates itself (drag: fluid_forces.py:103-142, gravity:
+    gravity_forces.py:66-148).  It sits in the ensemble's registry like the reference's auto-registered force
+    objects (dynamic_beam_model.py:220-241); switching ``enabled`` off takes effect at the next call, because the
+    registry is re-read on every call (force_registry.py:66-67)."""
+
+    def __init__(self, kind: str):
+        self.kind = kind
+        self.enabled = True
+
+    def is_enabled(self) -> bool:
+        return self.enabled
+
+    def compute_forces(self, x, t):
+        raise RuntimeError(f"the built-in {self.kind} force is evaluated inside the RHS kernel, not on the host")
+
+
+class BatchedForceRegistry:
+    """ForceRegistry of an ensemble (reference: models/force_registry.py:6-88, same methods and semantics): force
+    components whose ``compute_forces(x, t)`` maps the reduced states ``x[B, 2n]`` (a torch tensor on the ensemble's
+    device) to generalised forces ``[B, n]``.  ``register`` ignores a component that is disabled at that moment
+    (:20-21); the aggregate re-checks ``is_enabled()`` on every call (:66-67); ``get_registered_forces`` returns a copy."""
+
+    def __init__(self):
+        self._forces = []
+
+    def register(self, force_instance) -> None:
+        if force_instance.is_enabled():
+            self._forces.append(force_instance)
+
+    def unregister(self, force_instance) -> bool:
+        if force_instance in self._forces:
+            self._forces.remove(force_instance)
+            return True
+        return False
+
+    def clear(self) -> None:
+        self._forces.clear()
+
+    def get_registered_forces(self):
+        return self._forces.copy()
+
+    def __len__(self) -> int:
+        return len(self._forces)
+
+    def __contains__(self, force_instance) -> bool:
+        return force_instance in self._forces
+
+
 class BeamEnsemble:
     """B independent beams stepped together on one GPU.
 
@@ -112,6 +161,21 @@ class BeamEnsemble:
         self.state = torch.zeros((n_beams, 2, self.n_node, 4), dtype=dtype, device=self.device)
         self.time = 0.0
         self._lib = nat.load()
+        # functional composition (step_composed): the built-in forces appear in the registry as markers, user forces
+        # are torch callables; plans with a built-in force switched off are created on demand
+        self._plan_args = dict(n_beams=n_beams, node_bc=node_bc, corrected_axial=corrected_axial,
+                               dtype="f64" if dtype == torch.float64 else "f32", device=self.device.index)
+        self._fps = fps if fps else [fp_of(0)]
+        self._plans = {}
+        self.force_registry = BatchedForceRegistry()
+        self._auto_drag = self._auto_gravity = None
+        if any(f.enable_fluid_effects for f in self._fps):
+            self._auto_drag = _FusedForce("drag")
+            self.force_registry.register(self._auto_drag)
+        if any(f.enable_gravity_effects for f in self._fps):
+            self._auto_gravity = _FusedForce("gravity")
+            self.force_registry.register(self._auto_gravity)
+        self._plans[(self._auto_drag is not None, self._auto_gravity is not None)] = self.plan
 
     @classmethod
     def from_dataframes(cls, frames: Sequence, force_params=None, **kwargs):
@@ -397,6 +461,96 @@ class BeamEnsemble:
         self._keep = keep + [K, ref, work]
         self.time = float(t_end.value)
         return self.time
+
+    # ------------------------------------------------------------------ functional composition
+    def _plan_with(self, drag_on: bool, gravity_on: bool):
+        """The ensemble's plan with the built-in drag / gravity terms of the RHS kernel switched on or off."""
+        key = (bool(drag_on), bool(gravity_on))
+        if key not in self._plans:
+            fps, per = self._fps, len(self._fps) > 1
+            pick = (lambda f: [f(p) for p in fps]) if per else (lambda f: f(fps[0]))
+            with torch.cuda.device(self.device):
+                self._plans[key] = nat.Plan(
+                    self.columns, fluid_density=pick(lambda p: p.fluid_density),
+                    enable_fluid=pick(lambda p: bool(p.enable_fluid_effects and drag_on)),
+                    gravity=pick(lambda p: p.get_gravity_vector()),
+                    enable_gravity=pick(lambda p: bool(p.enable_gravity_effects and gravity_on)), **self._plan_args)
+        return self._plans[key]
+
+    def step_composed(self, n_steps: int, dt: float, forces_func=None, u=None, impulse_amp=None,
+                      impulse_duration: float = 0.01, impulse_index: int = -2, t0: Optional[float] = None) -> float:
+        """RK4 with the reference's functional force composition, batched (dynamic_beam_model.py:243-274, 343-362):
+        xdot = [v ; Minv(-k(q) + forces(x, 0.0) + u(t))] with
+
+        forces_func  ``callable(x[B, 2n], t) -> [B, n]`` (torch, on the ensemble's device) used INSTEAD of the registry,
+                     as ``create_system_func(forces_func)`` does (:253-254), called with t = 0.0 (:265, quirk B-3);
+                     None: the aggregate of ``self.force_registry`` -- the enabled built-in drag / gravity markers run
+                     fused inside the RHS kernel, every other enabled component (``compute_forces(x, t)``, e.g. the
+                     reference's StateAwareForce, tests/test_advanced_composition.py:36-65) is summed on the device;
+                     ``enabled`` is re-read at EVERY evaluation (force_registry.py:66-67)
+        u            ``[B, n]`` held input, or ``callable(t) -> [B, n]`` evaluated at every stage time (:357-360)
+        impulse_*    the examples' tip impulse on top (as in ``step``).
+
+        Stage-split path: per stage the state is unpacked to the reduced ordering, the callables run as torch ops,
+        and one crb_rk4_stage launch takes their sum as its input force.  Returns the clock (accumulated by addition).
+        """
+        if t0 is not None:
+            self.time = float(t0)
+        desc = nat.InputDesc()
+        desc.kind = nat.CRB_INPUT_NONE
+        keep = []
+        if impulse_amp is not None:
+            self._impulse(desc, keep, impulse_amp, impulse_duration, impulse_index)
+        acc, bufs = torch.empty_like(self.state), (torch.empty_like(self.state), torch.empty_like(self.state))
+        zeros = torch.zeros((self.n_beams, self.n_node, 4), dtype=self.dtype, device=self.device)
+        u_held = None if (u is None or callable(u)) else self._dev(u, (self.n_beams, self.n))
+        t = self.time
+        dt = float(dt)
+        with torch.cuda.device(self.device):
+            for _ in range(int(n_steps)):
+                cur = self.state
+                for s, ts in enumerate((t, t + 0.5 * dt, t + 0.5 * dt, t + dt)):   # crb_step_rk4's clock convention
+                    total = None
+                    if forces_func is not None:
+                        plan = self._plan_with(False, False)
+                        total = self._force_tensor(forces_func(self.unpack_state(cur), 0.0))
+                    else:
+                        drag_on = grav_on = False
+                        x_red = None
+                        for force in self.force_registry.get_registered_forces():
+                            if not force.is_enabled():
+                                continue
+                            if force is self._auto_drag:
+                                drag_on = True
+                            elif force is self._auto_gravity:
+                                grav_on = True
+                            else:
+                                if x_red is None:
+                                    x_red = self.unpack_state(cur)
+                                part = self._force_tensor(force.compute_forces(x_red, 0.0))
+                                total = part.clone() if total is None else total + part
+                        plan = self._plan_with(drag_on, grav_on)
+                    if u is not None:
+                        ut = self._force_tensor(u(ts)) if callable(u) else u_held
+                        total = ut if total is None else total + ut
+                    u_stage = zeros if total is None else self.pack_vec(total)
+                    nxt = bufs[s & 1]
+                    nat.check(self._lib.crb_rk4_stage(plan.h, self._ptr(self.state), self._ptr(cur), self._ptr(acc),
+                                                      self._ptr(nxt), self._ptr(u_stage), s, float(ts), dt, C.byref(desc),
+                                                      self._stream()))
+                    cur = nxt
+                t = t + dt
+        self._keep = keep + [acc, bufs, zeros]
+        self.time = t
+        return self.time
+
+    def _force_tensor(self, f) -> torch.Tensor:
+        """A user callable's result as a [B, n] tensor of the ensemble's dtype and device; the wrong shape is a
+        ValueError (the reference's M_inv.dot raises a dimension mismatch, dynamic_beam_model.py:270)."""
+        f = torch.as_tensor(f, dtype=self.dtype, device=self.device)
+        if tuple(f.shape) != (self.n_beams, self.n):
+            raise ValueError(f"dimension mismatch: force of shape {tuple(f.shape)} for {(self.n_beams, self.n)} position DOFs")
+        return f.contiguous()
 
     def gather(self, node: int, param: str, velocity: bool = False) -> torch.Tensor:
         out = torch.empty((self.n_beams,), dtype=self.dtype, device=self.device)

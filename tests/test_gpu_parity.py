@@ -1160,3 +1160,127 @@ def test_ensemble_with_per_beam_lengths_boundary_conditions_and_force_params(siz
     # one gain matrix for the whole ensemble needs one free-DOF set
     with pytest.raises(Exception, match="one free-DOF set"):
         ens.step_feedback(1, 5e-6, np.zeros((ens.n, 2 * ens.n)))
+
+
+# ------------------------------------------------------------------ batched functional composition (SURVEY §7 "hard parts")
+class _TipSpringDamper:
+    """The reference's StateAwareForce (tests/test_advanced_composition.py:36-65) restated for an ensemble: a
+    spring-damper on the last transverse DOF, on torch tensors x[B, 2n] -> [B, n]."""
+
+    def __init__(self, stiffness=1000.0, damping=10.0, enabled=True):
+        self.stiffness, self.damping, self.enabled = stiffness, damping, enabled
+
+    def compute_forces(self, x, t):
+        assert t == 0.0            # the reference passes 0.0 as the force time (dynamic_beam_model.py:265)
+        n = x.shape[1] // 2
+        f = torch.zeros((x.shape[0], n), dtype=x.dtype, device=x.device)
+        f[:, n - 2] = -self.stiffness * x[:, n - 2] - self.damping * x[:, n + n - 2]
+        return f
+
+    def is_enabled(self):
+        return self.enabled
+
+
+def _rk4_over_oracle(rhs, x, t, dt, steps):
+    """classical RK4 with the clock convention of crb_step_rk4 (t accumulates by addition) over rhs(t, x)"""
+    for _ in range(steps):
+        th, t1 = t + 0.5 * dt, t + dt
+        k1 = rhs(t, x)
+        k2 = rhs(th, x + 0.5 * dt * k1)
+        k3 = rhs(th, x + 0.5 * dt * k2)
+        k4 = rhs(t1, x + dt * k3)
+        x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+        t = t1
+    return x, t
+
+
+@pytest.mark.parametrize("n_e,kind", [(8, "mixed"), (70, "nonlinear")])
+def test_batched_functional_composition_matches_oracle(n_e, kind):
+    """step_composed: registry forces (built-in drag + gravity fused in the kernel, a state-dependent user force on the
+    device), a time-varying input u(t) and the tip impulse, against RK4 over the oracle RHS with the same forces;
+    `enabled` toggled between calls takes effect (force_registry.py:66-67); a forces_func REPLACES the registry
+    (dynamic_beam_model.py:253-254)."""
+    kinds = ["nonlinear" if i % 2 else "linear" for i in range(n_e)] if kind == "mixed" else kind
+    cols = nitinol_columns(n_e, kinds)
+    kw = dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True)
+    B, dt = 3, 2e-5
+    ens = ensemble(cols, B, kw)
+    n = ens.n
+    assert len(ens.force_registry) == 2          # the two built-in markers, like the reference's auto-registration
+    spring = _TipSpringDamper(stiffness=800.0, damping=5.0)
+    off = _TipSpringDamper(enabled=False)
+    ens.force_registry.register(spring)
+    ens.force_registry.register(off)             # register() ignores a disabled component (force_registry.py:20-21)
+    assert len(ens.force_registry) == 3 and off not in ens.force_registry
+    forces = ens.force_registry.get_registered_forces()
+    forces.clear()
+    assert len(ens.force_registry) == 3          # a copy was returned (:49)
+    rng = np.random.default_rng(n_e)
+    x0 = rng.normal(0.0, 1e-6, (B, 2 * n))
+    amps = np.array([0.05, 0.1, 0.2])
+    w = 2 * np.pi * 900.0
+    dof = n - 5
+
+    def u_of_t(t):                               # callable input u(t) (dynamic_beam_model.py:357-360)
+        u = torch.zeros((B, n), dtype=torch.float64, device=ens.device)
+        u[:, dof] = 0.02 * float(np.sin(w * t)) * torch.arange(1, B + 1, device=ens.device)
+        return u
+
+    obs = {(d, g): oracle_beam(cols, fluid_density=1000.0, enable_fluid=d, enable_gravity=g)
+           for d in (True, False) for g in (True, False)}
+
+    def oracle_rhs(b, drag, grav, use_spring, t_imp_end):
+        def rhs(t, x):
+            u = np.zeros(n)
+            u[dof] = 0.02 * np.sin(w * t) * (b + 1)
+            if t < t_imp_end:
+                u[n - 2] += amps[b]
+            if use_spring:
+                u[n - 2] += -800.0 * x[n - 2] - 5.0 * x[2 * n - 2]
+            return obs[(drag, grav)].rhs(x, u)
+        return rhs
+
+    ens.set_state(x0)
+    imp_end = 13.5 * dt
+    ens.step_composed(20, dt, u=u_of_t, impulse_amp=amps, impulse_duration=imp_end)
+    ens._auto_drag.enabled = False               # toggled at run time: the next call runs without the fused drag
+    spring.enabled = False
+    ens.step_composed(10, dt, u=u_of_t, impulse_amp=amps, impulse_duration=imp_end)
+    spring.enabled = True
+    ens._auto_gravity.enabled = False
+    ens.step_composed(10, dt, u=u_of_t, impulse_amp=amps, impulse_duration=imp_end)
+    got = ens.unpack_state().cpu().numpy()
+    assert abs(ens.time - 40 * dt) < 1e-15
+    for b in range(B):
+        x, t = _rk4_over_oracle(oracle_rhs(b, True, True, True, imp_end), x0[b], 0.0, dt, 20)
+        x, t = _rk4_over_oracle(oracle_rhs(b, False, True, False, imp_end), x, t, dt, 10)
+        x, t = _rk4_over_oracle(oracle_rhs(b, False, False, True, imp_end), x, t, dt, 10)
+        assert_blocks(got[b], x, ens.free_index, 1e-9, what=("registry", b))
+    # forces_func replaces the registry: only the user force acts, the built-in terms are off
+    ens.set_state(x0)
+    ens.step_composed(15, dt, forces_func=lambda x, t: spring.compute_forces(x, t), u=0.01 * np.ones((B, n)), t0=0.0)
+    got = ens.unpack_state().cpu().numpy()
+    for b in range(B):
+        def rhs(t, x, b=b):
+            u = np.full(n, 0.01)
+            u[n - 2] += -800.0 * x[n - 2] - 5.0 * x[2 * n - 2]
+            return obs[(False, False)].rhs(x, u)
+
+        x, _ = _rk4_over_oracle(rhs, x0[b], 0.0, dt, 15)
+        assert_blocks(got[b], x, ens.free_index, 1e-9, what=("forces_func", b))
+    # a user force of the wrong shape is a ValueError (test_advanced_composition.py:341 accepts it), exceptions propagate
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        ens.step_composed(1, dt, forces_func=lambda x, t: torch.zeros((B, n + 1), device=ens.device))
+
+    def boom(x, t):
+        raise RuntimeError("user force failed")
+
+    with pytest.raises(RuntimeError, match="user force failed"):
+        ens.step_composed(1, dt, forces_func=boom)
+    # with nothing but the built-in forces the composed path equals the fused stepper
+    a, b2 = ensemble(cols, B, kw), ensemble(cols, B, kw)
+    a.set_state(x0)
+    b2.set_state(x0)
+    a.step_composed(12, dt, impulse_amp=amps)
+    b2.step(12, dt, impulse_amp=amps)
+    assert_blocks(a.unpack_state().cpu().numpy(), b2.unpack_state().cpu().numpy(), a.free_index, 1e-11)
