@@ -43,6 +43,13 @@ BYTES_PER_ELEM_STEP = {"f64": 96.0, "f32": 48.0}
 MIN_TIMED_S = 0.05             # shorter timed regions are repeated and the median reported
 
 CONFIGS = {
+    # BASELINE configs[0], the reference's own CPU-runnable case: ONE 10-element linear cantilever under gravity
+    # integrated for 1 s (examples/beam_comparison_gravity.py; the reference hands it to solve_ivp(LSODA): 207 s,
+    # BASELINE.md §2).  Here: crb_step_implicit, h = 1e-4 s, 10000 steps = 1 s in ONE launch.  A parity-test case and a
+    # wall-time line, not the metric configuration (one beam cannot fill a GPU).
+    "config1": dict(beams=1, total=1, elems=10, kind="linear", drag=False, gravity=True, x0=False, implicit=True,
+                    dt=1e-4, steps=10000, scaling="weak",
+                    label="1 beam x 10 elem, linear + gravity, implicit midpoint h = 1e-4 s (1 s per 10000 steps), fp64"),
     # name: beams per GPU (weak) / total (strong), elements, element type, forces, random x0, defaults
     "config3": dict(beams=4096, total=4096, elems=256, kind="nonlinear", drag=True, gravity=False, x0=False,
                     scaling="weak",
@@ -73,7 +80,7 @@ def parse(argv=None):
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: the config's beams on EVERY GPU; strong: BASELINE's total (config3/4 4096, config5 16384) "
                          "sharded over the GPUs.  Default: the config's (config4: strong, the others weak)")
-    ap.add_argument("--launch-steps", type=int, default=100,
+    ap.add_argument("--launch-steps", type=int, default=None,
                     help="RK4 steps fused per launch (0 = all of --steps); warmup uses launches of the same size, so "
                          "every stepper launch of a run is identical and rocprof's per-kernel average is the launch time")
     ap.add_argument("--repeats", type=int, default=0,
@@ -91,6 +98,8 @@ def parse(argv=None):
         args.steps = cfg.get("steps", 1000)
     if args.scaling is None:
         args.scaling = cfg["scaling"]
+    if args.launch_steps is None:
+        args.launch_steps = 0 if cfg.get("implicit") else 100
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
     return args
@@ -289,7 +298,9 @@ def worker(args):
     per_launch = min(per_launch, args.steps)
 
     def advance(k):
-        if gain is None:
+        if cfg.get("implicit"):
+            ens.step_implicit(k, dt, n_iter=2, impulse_amp=amps)
+        elif gain is None:
             ens.step(k, dt, impulse_amp=amps)
         else:
             ens.step_feedback(k, dt, gain, impulse_amp=amps)
@@ -373,7 +384,15 @@ def worker(args):
         b = B - 1
         ob = oracle_beam(params[b] if args.hetero else cols, **okw)
         x0b = np.zeros(2 * ob.n) if x0 is None else x0n[b]
-        if gain is None:
+        if cfg.get("implicit"):
+            ref = ob.implicit(x0b, dt, args.steps, n_iter=2, amp=float(amps[b].item()))
+            check["simulated_seconds"] = args.steps * dt
+            check["reference_lsoda_wall_s_per_simulated_s"] = 207.0   # BASELINE.md §2 (survey container, 1 core)
+            g8 = os.path.join(ROOT, "tests", "golden", "g8_lsoda.npz")
+            if os.path.exists(g8) and abs(args.steps * dt - 0.1) < 1e-9:
+                z = np.load(g8)
+                check["tip_w_lsoda_tight_reference_rhs"] = float(z["lin10_grav/x_tight"][-1][ob.n - 2])
+        elif gain is None:
             ref = ob.rk4_impulse(x0b, dt, args.steps, float(amps[b].item()))
         else:
             ref = ob.rk4_feedback(x0b, dt, args.steps, gain.double().cpu().numpy(), amp=float(amps[b].item()))
@@ -400,7 +419,8 @@ def worker(args):
         algo_bytes_launch = BYTES_PER_ELEM_STEP[args.dtype] * B * ne * per_launch
         achieved = algo_bytes_launch / avg_launch_s / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "crb_step_lean_kernel",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "crb_implicit_kernel" if cfg.get("implicit") else "crb_step_lean_kernel",
                     "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_launch,
                     "valu_issue_frac": None}
     else:

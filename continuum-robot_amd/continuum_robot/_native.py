@@ -118,6 +118,8 @@ def load():
     L.crb_solve_rk45_eval.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(InputDesc), vp, vp,
                                       i32, C.POINTER(RecordDesc), C.c_double, C.c_double, i32, vp]
     L.crb_feedback_force.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.crb_step_implicit.argtypes = [vp, vp, C.c_double, C.c_double, i32, i32, C.POINTER(InputDesc),
+                                    C.POINTER(RecordDesc), C.POINTER(C.c_double), vp]
     L.crb_rk4_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.POINTER(InputDesc), vp]
     L.crb_feedback_work_bytes.argtypes = [vp]
     L.crb_feedback_work_bytes.restype = C.c_size_t

@@ -366,6 +366,49 @@ class BeamEnsemble:
         self.time = t_end.value
         return (self.time, samples) if record is not None else self.time
 
+    def step_implicit(self, n_steps: int, h: float, n_iter: int = 2, impulse_amp=None, impulse_duration: float = 0.01,
+                      impulse_index: int = -2, held_force=None, t0: Optional[float] = None, record=None,
+                      record_every: int = 1):
+        """Advance the resident state by ``n_steps`` steps of size ``h`` of the implicit midpoint rule in one launch
+        (crb_step_implicit): the stiff end of the reference's call sites -- the examples integrate 1 s with
+        ``solve_ivp(method="LSODA")`` (example_utilities.py:153-159) because explicit steppers are limited to
+        dt <= ~7e-5 s; here h = 1e-3 ... 1e-4 s is stable.  ``n_iter`` modified-Newton iterations per step (2
+        reproduces the converged step); inputs are sampled at the step midpoint.  ``record`` as in ``step``.
+        Displacements converge at second order in h; velocity components of modes with |lambda| h >> 1 are not
+        resolved (amplitude kept, phase not)."""
+        if t0 is not None:
+            self.time = float(t0)
+        desc = nat.InputDesc()
+        desc.kind = nat.CRB_INPUT_NONE
+        keep = []
+        if impulse_amp is not None:
+            self._impulse(desc, keep, impulse_amp, impulse_duration, impulse_index)
+        if held_force is not None:
+            held = self.pack_vec(held_force)
+            desc.f_held = held.data_ptr()
+            keep.append(held)
+        t_end = C.c_double(0.0)
+        rec, samples = None, None
+        if isinstance(record, str) and record == "all":
+            samples = torch.zeros((int(n_steps) // int(record_every),) + tuple(self.state.shape), dtype=self.dtype,
+                                  device=self.device)
+            rec = nat.RecordDesc(0, -1, 0, int(record_every), samples.data_ptr())
+            keep.append(samples)
+        elif record is not None:
+            node, param = record
+            vel = param.startswith("d") and param.endswith("_dt")
+            samples = torch.zeros((self.n_beams, int(n_steps) // int(record_every)), dtype=self.dtype, device=self.device)
+            rec = nat.RecordDesc(int(vel), int(node), _PARAM[param[1:-3] if vel else param], int(record_every),
+                                 samples.data_ptr())
+            keep.append(samples)
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.crb_step_implicit(self.plan.h, self._ptr(self.state), self.time, float(h), int(n_steps),
+                                                  int(n_iter), C.byref(desc), C.byref(rec) if rec is not None else None,
+                                                  C.byref(t_end), self._stream()))
+        self._keep = keep
+        self.time = t_end.value
+        return (self.time, samples) if record is not None else self.time
+
     def solve_rk45(self, t_end: float, rtol: float = 1e-3, atol: float = 1e-6, impulse_amp=None,
                    impulse_duration: float = 0.01, impulse_index: int = -2, held_force=None,
                    first_step=None, t0: Optional[float] = None, max_steps: int = 0, record=None, t_eval=None):

@@ -31,6 +31,9 @@ struct AsmParams {
     const double* fluid_density_b;  // [nb]
     const uint32_t* flags_b;    // [nb]
     size_t free_stride, grav_stride;
+    // alpha != 0: factorise A = M + alpha K0 (K0 = linear element stiffness) instead of M -- the iteration matrix of
+    // the implicit stepper (crb_stiff.h); slot_out is then null (the slot tables are the plan's)
+    double alpha;
     void* slot_out;             // SlotConst<T>[nb][S]
     double* lv64; void* lvT;    // [nb][levels_full][S][10]   (lv64 may be null)
     double* fin64_all;          // [levels_full+1][S][6] final inverse after k levels (beam 0 only; may be null)
@@ -89,12 +92,17 @@ __global__ void __launch_bounds__(1024) crb_assemble_kernel(const AsmParams p) {
         }
         sc.half_mass = ((flags & 2u) && j < ne) ? T(0.5 * (pRho[j] * pA[j] * pL[j])) : T(0);
         sc.grav = p.grav[size_t(beam) * p.grav_stride + j];
-        static_cast<SlotConst<T>*>(p.slot_out)[tab + j] = sc;
+        if (p.slot_out) static_cast<SlotConst<T>*>(p.slot_out)[tab + j] = sc;
 
         // ---- mass matrix, node-block form, with the boundary-condition masks
         const int el = node - 1, er = node;
         if (el >= 0 && el < ne) mass_add_as_left_elem(cur, pL[el], pRho[el] * pA[el], j >= 1);
         if (er < ne) mass_add_as_right_elem(cur, pL[er], pRho[er] * pA[er]);
+        if (p.alpha != 0.0) {
+            if (el >= 0 && el < ne) stiff_add_as_left_elem(cur, pL[el], pE[el] * pA[el], pE[el] * pI[el], p.alpha, j >= 1);
+            if (er < ne)   // (the shipped nonlinear f1 has no u2 coupling unless CRB_CORRECTED_AXIAL)
+                stiff_add_as_right_elem(cur, pL[er], pE[er] * pA[er], pE[er] * pI[er], p.alpha, !pNl[er] || (flags & 4u) != 0);
+        }
         const bool hl = j >= 1, hr = j + 1 < p.S;
         mass_apply_masks(cur, fm(node, 0), fm(node, 1), fm(node, 2), hl && fm(node - 1, 0), hl && fm(node - 1, 1),
                          hl && fm(node - 1, 2), hr && fm(node + 1, 0), hr && fm(node + 1, 1), hr && fm(node + 1, 2));

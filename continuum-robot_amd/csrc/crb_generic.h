@@ -162,10 +162,13 @@ struct SolveCoef {
 
 // One evaluation of a = Minv(-k(q) + f_drag + f_grav + u) for this thread's node.
 // Returns k(q) in `a` (no solve) when KQ_ONLY.
-template <typename T, int LV, bool KQ_ONLY, bool LEAN>
+// STIFF (implicit stepper, crb_stiff.h): the solve tables in `cf` are those of A = M + alpha K0 and the right-hand side
+// gains + alpha K0 z (K0 = the linear element stiffness, z = the current acceleration iterate), so that the result is
+// the next iterate of  a <- Ainv (F(q, v) + alpha K0 a).
+template <typename T, int LV, bool KQ_ONLY, bool LEAN, bool STIFF = false>
 __device__ __forceinline__ void stage_accel(const KParams<T>& p, const Lds<T>& lds, const SlotConst<T>& sc,
                                             const SolveCoef<T, LV>& cf, const Topo& tp, const T q[3], const T v[3],
-                                            const T uadd[3], T a[3]) {
+                                            const T uadd[3], T a[3], const T* z = nullptr, T alpha = T(0)) {
     const int NT = lds.NT;
     // LEAN kernels are only launched for plans without gravity (and calls without a held input)
     const bool drag_on = (p.flags & 1u) != 0, grav_on = !LEAN && (p.flags & 2u) != 0, corrected = (p.flags & 4u) != 0;
@@ -181,6 +184,16 @@ __device__ __forceinline__ void stage_accel(const KParams<T>& p, const Lds<T>& l
     }
     T fl[3], fr[3];
     elem_force<T>(sc.elem, ql, q, corrected, fl, fr);
+    if (STIFF) {   // - alpha K0 z joins the internal force (it is subtracted from the right-hand side below)
+        T zl[3], lin[5] = {T(0), T(0), T(0), T(0), T(0)}, kl[3], kr[3];
+        const T zz[3] = {z[0], z[1], z[2]};
+        neighbours<T>(tp, lds.r1, NT, 1, cross1, zz, true, false, zl, dummy);
+        elem_linear_coefs<T>(sc.elem.c, sc.elem.kind, lin);
+        elem_force_linear<T>(lin, zl, zz, kl, kr);
+        if (sc.elem.kind == KIND_NONLINEAR && !corrected) kl[0] = lin[0] * zl[0];   // tangent of the shipped f1: no u2 term
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { fl[c] -= alpha * kl[c]; fr[c] -= alpha * kr[c]; }
+    }
 
     T gseg[2] = {T(0), T(0)};
     if (!KQ_ONLY && grav_on && sc.half_mass != T(0)) {

@@ -293,6 +293,51 @@ CRB_HD void mass_add_as_left_elem(NodeBlocks& n, double L, double rhoA, bool has
     }
 }
 
+// alpha * K0 of one element added to the node blocks, K0 = the element's tangent stiffness AT q = 0 -- the
+// iteration matrix A = M + alpha K0 of the implicit stepper (crb_stiff.h) has M's block structure.  For a linear
+// element K0 is its stiffness (segments.py:39-62); from elem_force_linear, on [w, phi] the four 2x2 blocks are
+//   K11 = [[c1,-c2],[-c2,c3]]  K12 = [[-c1,-c2],[c2,c4]]  K21 = [[-c1,c2],[-c2,c4]]  K22 = [[c1,c2],[c2,c3]]
+// with c1 = 12EI/L^3, c2 = 6EI/L^2, c3 = 4EI/L, c4 = 2EI/L, and [[c0,-c0],[-c0,c0]], c0 = EA/L, on the axial DOFs.
+// A nonlinear element has the same tangent at q = 0, EXCEPT that the shipped f1 (segments.py:178-208, SURVEY
+// App. B-1) lacks the -EA/L u2 coupling: d f1 / d u2 = 0, i.e. the axial block is [[c0, 0],[-c0, c0]] (`axial_12`
+// false) and A is not symmetric; the cyclic reduction carries the sub- and super-diagonal separately anyway.
+CRB_HD void stiff_add_as_right_elem(NodeBlocks& n, double L, double EA, double EI, double alpha, bool axial_12) {
+    // this node is the element's first node: K11 on the diagonal, K12 to the right
+    const double c0 = alpha * EA / L, c1 = alpha * 12 * EI / (L * L * L), c2 = alpha * 6 * EI / (L * L), c3 = alpha * 4 * EI / L,
+                 c4 = alpha * 2 * EI / L;
+    n.b_ax += c0;
+    if (axial_12) n.c_ax += -c0;
+    n.B[0] += c1; n.B[1] += -c2; n.B[2] += -c2; n.B[3] += c3;
+    n.C[0] += -c1; n.C[1] += -c2; n.C[2] += c2; n.C[3] += c4;
+}
+CRB_HD void stiff_add_as_left_elem(NodeBlocks& n, double L, double EA, double EI, double alpha, bool has_left_node) {
+    // this node is the element's second node: K22 on the diagonal, K21 to the left
+    const double c0 = alpha * EA / L, c1 = alpha * 12 * EI / (L * L * L), c2 = alpha * 6 * EI / (L * L), c3 = alpha * 4 * EI / L,
+                 c4 = alpha * 2 * EI / L;
+    n.b_ax += c0;
+    n.B[0] += c1; n.B[1] += c2; n.B[2] += c2; n.B[3] += c3;
+    if (has_left_node) {
+        n.a_ax += -c0;
+        n.A[0] += -c1; n.A[1] += c2; n.A[2] += -c2; n.A[3] += c4;
+    }
+}
+
+// linear coefficient pack {EA/L, 12EI/L^3, 6EI/L^2, 4EI/L, 2EI/L} of an element from EITHER pack of ElemCoef
+// (the nonlinear pack holds {L, EA/L^2, 0.1EA/L^3, 2EI/L^3, EA/(2L^2), EI/L^2})
+template <typename T>
+CRB_HD void elem_linear_coefs(const T* c, int kind, T out[5]) {
+    if (kind == KIND_NONLINEAR) {
+        const T L = c[0];
+        out[0] = c[1] * L;
+        out[1] = T(6) * c[3];
+        out[2] = T(6) * c[5];
+        out[3] = T(4) * c[5] * L;
+        out[4] = T(2) * c[5] * L;
+    } else {   // KIND_LINEAR (KIND_NONE: all zero already)
+        for (int i = 0; i < 5; ++i) out[i] = c[i];
+    }
+}
+
 // Boundary conditions (euler_bernoulli_beam.py:240-265) in place of physically removing
 // rows/columns: a constrained DOF keeps its slot, its row/column become the identity.
 // free_* are this node's masks, l_* / r_* the neighbours' (a missing neighbour = not free).

@@ -26,6 +26,30 @@ static int fail(int code, const std::string& msg) {
         if (e__ != hipSuccess) return fail(CRB_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// ---- device-side assembly (crb_assemble_kernel) -------------------------------------------------
+template <typename X>
+struct DevBuf {
+    X* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(X)) == hipSuccess ? 0 : -1; }
+    int upload(const X* h, size_t n) {
+        if (alloc(n)) return -1;
+        return (!n || hipMemcpy(p, h, n * sizeof(X), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
+    }
+};
+// The assembly kernel's inputs stay on the device for the life of the plan: the implicit stepper factorises
+// A = M + alpha K0 from them for every new step size (crb_step_implicit).
+struct AsmInputs {
+    DevBuf<double> dL, dE, dI, dRho, dA, dWet, dCd, dFd, dNormScratch;
+    DevBuf<uint8_t> dNl, dFree;
+    DevBuf<crb::GravTab> dGrav;
+    DevBuf<int32_t> dNe;
+    DevBuf<uint32_t> dFl;
+    crb::AsmParams a;   // the launch parameters of the plan's own assembly (pointers into the buffers above)
+    int nd = 1, threads = 64;
+    size_t smem = 0;
+};
+
 struct crb_plan {
     int device = -1, dtype = CRB_F64, B = 0;
     int n_elem = 0, n_node = 0, n_free = 0, off = 0, S = 0, G = 1, NT = 64;
@@ -44,6 +68,12 @@ struct crb_plan {
     std::vector<uint8_t> any_free;    // [3 n_node]: DOF free in at least one beam
     size_t free_index_stride = 0;     // d_free_index is [B][n_free] (padded with -1) when != 0
     void* d_gvec = nullptr;           // [B][2] per-beam gravity vector in the plan dtype, or null (shared gx, gy)
+    // implicit stepper: cyclic-reduction tables of A = M + alpha K0 for the step size last used (all levels: A is not
+    // as diagonally dominant as M, nothing is truncated)
+    AsmInputs* asm_in = nullptr;
+    mutable void* d_alevels = nullptr;   // [nd][levels_full][S][10]
+    mutable void* d_afinal = nullptr;    // [nd][S][6]
+    mutable double stiff_alpha = 0.0;    // alpha the tables above were built for (0 = none yet)
     int32_t* d_n_state = nullptr;     // [B] 2 * n_free_b, or null
     std::vector<double> h_levels, h_final, h_norms, h_mass, h_stiff;
     int first_nonlinear = -1;
@@ -68,18 +98,6 @@ extern "C" int crb_version(void) { return CRB_VERSION; }
 extern "C" const char* crb_last_error(void) { return g_err.c_str(); }
 
 namespace {
-
-// ---- device-side assembly (crb_assemble_kernel) -------------------------------------------------
-template <typename X>
-struct DevBuf {
-    X* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(X)) == hipSuccess ? 0 : -1; }
-    int upload(const X* h, size_t n) {
-        if (alloc(n)) return -1;
-        return (!n || hipMemcpy(p, h, n * sizeof(X), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
-    }
-};
 
 void mass_from_blocks(crb_plan* p, const std::vector<NodeBlocks>& blk) {
     const int n = int(p->free_index.size()), S = p->S;   // (beam 0's reduced size; n_free is the ensemble's maximum)
@@ -134,11 +152,14 @@ int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::
                     const std::vector<const BeamTopo*>& topo /* [nd] */, bool per_beam_topo) {
     const int S = p->S, ne = p->n_elem, lf = p->levels_full, nn = p->n_node;
     const crb_beam_desc* d = descs;
-    DevBuf<double> dL, dE, dI, dRho, dA, dWet, dCd, dFinAll, dNorms, dBlocks, dLv64, dFd;
-    DevBuf<uint8_t> dNl, dFree;
-    DevBuf<GravTab> dGrav;
-    DevBuf<int32_t> dNe;
-    DevBuf<uint32_t> dFl;
+    p->asm_in = new AsmInputs();
+    AsmInputs& in = *p->asm_in;
+    DevBuf<double>&dL = in.dL, &dE = in.dE, &dI = in.dI, &dRho = in.dRho, &dA = in.dA, &dWet = in.dWet, &dCd = in.dCd, &dFd = in.dFd;
+    DevBuf<uint8_t>&dNl = in.dNl, &dFree = in.dFree;
+    DevBuf<GravTab>& dGrav = in.dGrav;
+    DevBuf<int32_t>& dNe = in.dNe;
+    DevBuf<uint32_t>& dFl = in.dFl;
+    DevBuf<double> dFinAll, dNorms, dBlocks, dLv64;
     const int nt = per_beam_topo ? nd : 1;   // beams whose integer topology is uploaded
     std::vector<GravTab> grav(size_t(nt) * S);
     std::vector<uint8_t> free_dof(size_t(nt) * nn * 3);
@@ -207,7 +228,7 @@ int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::
         const int n = p->n_free;
         std::vector<int32_t> col(size_t(2) * n), row(n);
         for (int r = 0; r < n; ++r) {
-            const int f = p->free_index[r];
+            const int f = r < int(p->free_index.size()) ? p->free_index[r] : 0;   // (mixed plans: beam 0 may be shorter)
             row[r] = (f / 3) * 4 + (f % 3);
             col[r] = row[r];
             col[n + r] = p->n_node * 4 + row[r];
@@ -254,6 +275,7 @@ int device_assemble(crb_plan* p, const crb_beam_desc* descs, int nd, const std::
     const int used = pick_levels(p);
     if (used > MAX_LV)
         return fail(CRB_EUNSUPPORTED, "mass matrix needs more cyclic-reduction levels than the kernels carry in registers");
+    in.a = a; in.nd = nd; in.threads = nta; in.smem = smem;   // (kept for the implicit stepper's factorisations)
     // pass 2: the final inverses after `used` levels, straight into the steppers' table
     a.finT = p->d_final; a.fin_level = used; a.lv64 = nullptr; a.blocks0 = nullptr; a.fin64_all = nullptr;
     hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(nta), smem, nullptr, a);
@@ -643,6 +665,9 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         (void)hipFree(p->d_row_off);
         (void)hipFree(p->d_gvec);
         (void)hipFree(p->d_n_state);
+        (void)hipFree(p->d_alevels);
+        (void)hipFree(p->d_afinal);
+        delete p->asm_in;
     }
     delete p;
 }
@@ -1023,6 +1048,138 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     k.rec_out = static_cast<float*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
     if (lean_eligible(p, held)) return launch_lean<float>(p, k, st);
     return launch_beam<float, MODE_STEP>(p, k, st);
+}
+
+// ------------------------------------------------------------------ implicit stepper (crb_stiff.h)
+namespace {
+// (re)builds the cyclic-reduction tables of A = M + alpha K0 on `st` when the step size changed
+template <typename T>
+int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
+    if (p->stiff_alpha == alpha && p->d_alevels) return CRB_OK;
+    AsmInputs& in = *p->asm_in;
+    const int S = p->S, lf = p->levels_full, nd = in.nd;
+    if (!p->d_alevels) {
+        HIP_TRY(hipMalloc(&p->d_alevels, size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
+        HIP_TRY(hipMalloc(&p->d_afinal, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)));
+        if (in.dNormScratch.alloc(size_t(lf > 0 ? lf : 1))) return fail(CRB_EHIP, "crb_step_implicit: device allocation failed");
+    }
+    AsmParams a = in.a;
+    a.alpha = alpha;
+    a.slot_out = nullptr; a.lv64 = nullptr; a.fin64_all = nullptr; a.blocks0 = nullptr;
+    a.lvT = p->d_alevels; a.finT = p->d_afinal; a.fin_level = lf; a.norms = in.dNormScratch.p;
+    hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(in.threads), in.smem, st, a);
+    HIP_TRY(hipGetLastError());
+    p->stiff_alpha = alpha;
+    return CRB_OK;
+}
+
+template <typename T, int LV>
+int launch_implicit_lv(const crb_plan* p, const KParams<T>& k, const StiffParams<T>& q, hipStream_t st) {
+    const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);
+    const size_t smem = lds_bytes<T>(p->NT);
+    // one wave per SIMD: the thread's rows of A's tables (10 per level, up to 8 levels) stay in registers
+    if (p->NT <= 256) {
+        hipLaunchKernelGGL((crb_implicit_kernel<T, LV, 256, 1>), grid, block, smem, st, k, q);
+    } else {
+        if (int rc = allow_lds(crb_implicit_kernel<T, LV, 1024, 4>, smem)) return rc;
+        hipLaunchKernelGGL((crb_implicit_kernel<T, LV, 1024, 4>), grid, block, smem, st, k, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}
+template <typename T>
+int launch_implicit(const crb_plan* p, const KParams<T>& k, const StiffParams<T>& q, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: implicit stepper not built");
+#else
+    switch (p->levels_full) {   // A is factorised without truncation
+        case 0: return launch_implicit_lv<T, 0>(p, k, q, st);
+        case 1: return launch_implicit_lv<T, 1>(p, k, q, st);
+        case 2: return launch_implicit_lv<T, 2>(p, k, q, st);
+        case 3: return launch_implicit_lv<T, 3>(p, k, q, st);
+        case 4: return launch_implicit_lv<T, 4>(p, k, q, st);
+        case 5: return launch_implicit_lv<T, 5>(p, k, q, st);
+        case 6: return launch_implicit_lv<T, 6>(p, k, q, st);
+        case 7: return launch_implicit_lv<T, 7>(p, k, q, st);
+        case 8: return launch_implicit_lv<T, 8>(p, k, q, st);
+        default: return fail(CRB_EUNSUPPORTED, "crb_step_implicit: beams of more than 256 thread-carried nodes are not supported");
+    }
+#endif
+}
+
+template <typename T>
+int step_implicit_impl(const crb_plan* p, void* x, double t0, double h, int n_steps, int n_iter, const crb_input_desc* in,
+                       int imp_slot, int imp_dof, double duration, const void* amp, const void* held, void* rec_out,
+                       int rec_slot, int rec_comp, int rec_every, int rec_n, hipStream_t st) {
+    if (int rc = stiff_tables<T>(p, 0.25 * h * h, st)) return rc;
+    KParams<T> k = base_params<T>(p);
+    k.x = static_cast<T*>(x);
+    k.u_held = static_cast<const T*>(held);
+    k.amp = static_cast<const T*>(amp);
+    k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
+    k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
+    k.t0 = t0; k.dt = h; k.n_steps = n_steps;
+    k.rec_out = static_cast<T*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
+    StiffParams<T> q;
+    q.a_levels = static_cast<const T*>(p->d_alevels);
+    q.a_final = static_cast<const T*>(p->d_afinal);
+    q.alv_stride = p->asm_in->nd > 1 ? size_t(p->levels_full) * p->S * PCR_LEVEL_VALS : 0;
+    q.afin_stride = p->asm_in->nd > 1 ? size_t(p->S) * PCR_FINAL_VALS : 0;
+    q.h = h;
+    q.n_iter = n_iter;
+    return launch_implicit<T>(p, k, q, st);
+}
+}  // namespace
+
+extern "C" int crb_step_implicit(const crb_plan* p, void* x, double t0, double h, int n_steps, int n_iter,
+                                 const crb_input_desc* in, const crb_record_desc* rec, double* t_end, void* stream) {
+    if (int rc = need_device(p, "crb_step_implicit")) return rc;
+    if (!x) return fail(CRB_EINVAL, "crb_step_implicit: null pointer");
+    if (n_steps < 0) return fail(CRB_EINVAL, "crb_step_implicit: n_steps must be >= 0");
+    if (!(h > 0)) return fail(CRB_EINVAL, "crb_step_implicit: h must be positive");
+    if (n_iter < 1) return fail(CRB_EINVAL, "crb_step_implicit: n_iter must be >= 1");
+    int rec_slot = -1, rec_comp = 0, rec_every = 1, rec_n = 0;
+    void* rec_out = nullptr;
+    if (rec && rec->node == CRB_RECORD_ALL) {
+        if (rec->every < 1 || !rec->out) return fail(CRB_EINVAL, "crb_step_implicit: bad record description");
+        rec_n = n_steps / rec->every;
+        if (rec_n > 0) { rec_slot = REC_ALL_SLOTS; rec_every = rec->every; rec_out = rec->out; }
+    } else if (rec) {
+        if (rec->plane < 0 || rec->plane > 1 || rec->node < 0 || rec->node >= p->n_node || rec->dof < 0 || rec->dof > 2 ||
+            rec->every < 1 || !rec->out)
+            return fail(CRB_EINVAL, "crb_step_implicit: bad record description");
+        rec_n = n_steps / rec->every;
+        if (rec->node - p->off >= 0 && rec_n > 0) {
+            rec_slot = rec->node - p->off; rec_comp = rec->plane * 3 + rec->dof; rec_every = rec->every; rec_out = rec->out;
+        }
+    }
+    int imp_slot = -1, imp_dof = 0;
+    double duration = 0.0;
+    const void* amp = nullptr;
+    const void* held = nullptr;
+    if (in) {
+        held = in->f_held;
+        if (in->kind == CRB_INPUT_IMPULSE) {
+            if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp ||
+                !p->any_free[3 * in->node + in->dof])
+                return fail(CRB_EINVAL, "crb_step_implicit: bad impulse description");
+            imp_slot = in->node - p->off; imp_dof = in->dof; duration = in->duration; amp = in->amp;
+        } else if (in->kind != CRB_INPUT_NONE) {
+            return fail(CRB_EINVAL, "crb_step_implicit: unknown input kind");
+        }
+    }
+    if (t_end) {
+        double t = t0;
+        for (int i = 0; i < n_steps; ++i) t = t + h;
+        *t_end = t;
+    }
+    if (n_steps == 0) return CRB_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return p->dtype == CRB_F64
+               ? step_implicit_impl<double>(p, x, t0, h, n_steps, n_iter, in, imp_slot, imp_dof, duration, amp, held, rec_out,
+                                            rec_slot, rec_comp, rec_every, rec_n, st)
+               : step_implicit_impl<float>(p, x, t0, h, n_steps, n_iter, in, imp_slot, imp_dof, duration, amp, held, rec_out,
+                                           rec_slot, rec_comp, rec_every, rec_n, st);
 }
 
 static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage, int stage,

@@ -207,6 +207,23 @@ int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, 
                         const crb_input_desc* input, void* h, void* stats, int max_steps,
                         const crb_record_desc* rec, double eval_t0, double eval_dt, int n_eval, void* stream);
 
+/* Implicit fixed-step integration for the stiff end of the reference's call sites: the examples hand the beam RHS to
+ * solve_ivp(method="LSODA") for 1 s (examples/example_utilities.py:153-159, examples/lqr_control.py:117-125) because
+ * explicit steppers are stability-limited to dt <= ~7e-5 s.  n_steps steps of size h of the implicit midpoint rule
+ * (for linear systems the trapezoidal rule / Newmark average acceleration: A-stable, second order, no numerical
+ * damping) on M a = -k(q) + f_drag(v) + f_gravity(q) + u(t), each step solved by n_iter modified-Newton iterations
+ * with the constant matrix A = M + (h^2/4) K0 (K0 = element tangent stiffness at q = 0; cyclic reduction with
+ * multipliers factorised on the device whenever h changes); one launch, in place.
+ *   n_iter 1 is exact for linear elements without drag / gravity; 2 reproduces the converged step otherwise (the
+ *          state dependence of drag, gravity and the geometric stiffness is not stiff); every step starts from the
+ *          previous step's iterate, the first step of a call from 0.
+ *   input  sampled at the step MIDPOINT (impulse: on while t + h/2 < duration), held force as in crb_step_rk4.
+ *   rec    as crb_step_rk4_rec (may be NULL).  Beams of up to 256 thread-carried nodes.
+ * Modes with |lambda| h >> 1 are not resolved (their amplitude is kept, their phase is not): displacements converge
+ * at second order in h from h ~ 1e-3 s down, velocities only once h resolves the modes they contain. */
+int crb_step_implicit(const crb_plan* plan, void* x, double t0, double h, int n_steps, int n_iter,
+                      const crb_input_desc* input, const crb_record_desc* rec, double* t_end, void* stream);
+
 /* Feedback force of a whole ensemble, u = K (r - x) (FullStateLinear.compute_input,
  * control/full_state_linear.py:81; loop of examples/lqr_control.py:95-111), as one MFMA GEMM in the plan's dtype
  * (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32) with the gather from the state layout and the scatter into

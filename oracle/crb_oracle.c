@@ -23,6 +23,10 @@
  *   orc_rhs                  dynamic_beam_model.py:256-272, 294-328, 343-362
  *                            xdot = [v ; Minv(-k(q) + f(x, t=0) + u)]
  *   orc_rk4_feedback         the closed loop of examples/lqr_control.py:95-111 (u = K(r-x) per stage)
+ *   orc_implicit             OURS (like the RK4 loop: the reference has no integrator): implicit midpoint rule with
+ *                            a modified-Newton iteration, the CPU statement of crb_step_implicit -- the stiff end of
+ *                            the solve_ivp(LSODA) call sites (examples/example_utilities.py:153-159); pinned by
+ *                            tests/golden/g8_lsoda.npz (scipy LSODA at tight tolerances over the REFERENCE RHS)
  *   orc_rk4_*                fixed-step classical RK4 over orc_rhs.  The reference has no
  *                            integrator (callers use scipy.solve_ivp); the loop restated here
  *                            is the one in tests/golden/make_golden.py:rk4.
@@ -523,6 +527,90 @@ double orc_rk4_feedback(const orc_model* m, double* x, double t0, double dt, int
     }
 #undef ORC_FEEDBACK
     free(w);
+    return t;
+}
+
+/* Implicit midpoint rule on M a = F(q, v, t) = -k(q) + forces(x) + u(t):
+ *     a_m solves  M a_m = F(q_m, v_m, t_m),  q_m = q0 + h/2 v0 + alpha a_m,  v_m = v0 + h/2 a_m,  t_m = t0 + h/2,
+ *     q1 = q0 + h v0 + 2 alpha a_m,  v1 = v0 + h a_m,                        alpha = h^2/4
+ * (for linear systems the trapezoidal rule / Newmark average acceleration: A-stable, second order, no numerical
+ * damping), each step solved by n_iter iterations  a_m <- Ainv (F(q_m(a_m), v_m(a_m), t_m) + alpha K0 a_m),
+ * A = M + alpha K0, K0 = sum of the element tangent stiffnesses AT q = 0: the linear element stiffness
+ * (segments.py:32-62), and for a nonlinear element the same matrix except that the SHIPPED f1 (segments.py:178-208,
+ * SURVEY App. B-1) has no -EA/L u2 coupling: its row is [EA/L, 0, 0, 0, 0, 0] unless corrected_axial -- K0, and
+ * with it A, is then not symmetric.  Inputs are sampled at the step MIDPOINT (u[idx] = amp while t_m < duration), so a
+ * piecewise-constant input whose switch times fall on step boundaries is integrated exactly.
+ * Dense LU of A without pivoting (A is diagonally dominated by M / alpha-scaled K0 blocks; test sizes).
+ * a_guess [n] (may be NULL): in/out starting iterate (the previous step's a_m).  Returns the final clock. */
+double orc_implicit(const orc_model* m, double* x, double t0, double h, int n_steps, int n_iter, double amp,
+                    double duration, int idx, const double* u_held) {
+    const int n = m->n_red, nf = m->n_full, N = 2 * n;
+    if (idx < 0) idx += n;
+    const double alpha = 0.25 * h * h, hh = 0.5 * h;
+    /* K0 (reduced, dense) and A = M + alpha K0 */
+    double* Kf = (double*)calloc((size_t)nf * nf, sizeof(double));
+    for (int e = 0; e < m->n_seg; ++e) {
+        double Ke[36];
+        orc_elem_stiff_linear(m->L[e], m->E[e], m->I[e], m->A[e], Ke);
+        if (m->nonlinear[e] && !m->corrected_axial) Ke[0 * 6 + 3] = 0.0;   /* d f1 / d u2 of the shipped f1 at q = 0 */
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) Kf[(size_t)(3 * e + a) * nf + 3 * e + b] += Ke[a * 6 + b];
+    }
+    double* K0 = (double*)malloc((size_t)n * n * sizeof(double));
+    double* Am = (double*)malloc((size_t)n * n * sizeof(double));
+    orc_mass_dense(m, Am);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            K0[(size_t)i * n + j] = Kf[(size_t)m->red2full[i] * nf + m->red2full[j]];
+            Am[(size_t)i * n + j] += alpha * K0[(size_t)i * n + j];
+        }
+    free(Kf);
+    /* dense LU, A = L U in place (unit lower) */
+    for (int k = 0; k < n; ++k)
+        for (int i = k + 1; i < n; ++i) {
+            const double f = Am[(size_t)i * n + k] / Am[(size_t)k * n + k];
+            Am[(size_t)i * n + k] = f;
+            if (f != 0.0)
+                for (int j = k + 1; j < n; ++j) Am[(size_t)i * n + j] -= f * Am[(size_t)k * n + j];
+        }
+    double* w = (double*)malloc((size_t)(2 * N + 6 * n) * sizeof(double));
+    double *xm = w, *tmp = w + N, *u = w + 2 * N, *qp = u + n, *am = qp + n, *g = am + n, *kf = g + n;
+    double t = t0;
+    memset(am, 0, (size_t)n * sizeof(double));
+    for (int s = 0; s < n_steps; ++s) {
+        const double tm = t + hh;
+        for (int i = 0; i < n; ++i) u[i] = u_held ? u_held[i] : 0.0;
+        if (tm < duration) u[idx] += amp;
+        for (int i = 0; i < n; ++i) qp[i] = x[i] + hh * x[n + i];
+        /* starting iterate: the previous step's a_m (0 for the first step) */
+        for (int it = 0; it < n_iter; ++it) {
+            for (int i = 0; i < n; ++i) { xm[i] = qp[i] + alpha * am[i]; xm[n + i] = x[n + i] + hh * am[i]; }
+            orc_internal_force(m, xm, kf);
+            orc_forces(m, xm, tmp);
+            for (int i = 0; i < n; ++i) {
+                double k0a = 0.0;
+                for (int j = 0; j < n; ++j) k0a += K0[(size_t)i * n + j] * am[j];
+                g[i] = -kf[i] + tmp[i] + u[i] + alpha * k0a;
+            }
+            for (int i = 0; i < n; ++i) {          /* L y = g */
+                double v = g[i];
+                for (int k = 0; k < i; ++k) v -= Am[(size_t)i * n + k] * g[k];
+                g[i] = v;
+            }
+            for (int i = n - 1; i >= 0; --i) {     /* U a = y */
+                double v = g[i];
+                for (int k = i + 1; k < n; ++k) v -= Am[(size_t)i * n + k] * g[k];
+                g[i] = v / Am[(size_t)i * n + i];
+            }
+            memcpy(am, g, (size_t)n * sizeof(double));
+        }
+        for (int i = 0; i < n; ++i) {
+            x[i] = x[i] + h * x[n + i] + 2.0 * alpha * am[i];
+            x[n + i] = x[n + i] + h * am[i];
+        }
+        t = t + h;
+    }
+    free(w); free(K0); free(Am);
     return t;
 }
 

@@ -51,6 +51,9 @@ def lib():
         L.orc_rk4_feedback.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp, C.c_double, C.c_double,
                                        C.c_int]
         L.orc_rk4_feedback.restype = C.c_double
+        L.orc_implicit.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
+                                   C.c_double, C.c_int, _dp]
+        L.orc_implicit.restype = C.c_double
         L.orc_rk4_impulse_batch.argtypes = [C.c_void_p, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int,
                                             C.c_double, C.c_int, C.c_int]
         L.orc_rk4_impulse_batch.restype = C.c_int
@@ -203,6 +206,13 @@ class OracleBeam:
         r = _d(reference) if reference is not None else None
         lib().orc_rk4_feedback(self.h, _p(x), t0, dt, n_steps, _p(K), _p(r) if r is not None else None, amp, duration,
                                idx)
+        return x
+
+    def implicit(self, x0, h, n_steps, n_iter=3, amp=0.0, duration=0.01, idx=-2, t0=0.0, u_held=None):
+        """Implicit midpoint rule + modified Newton (orc_implicit), the CPU statement of crb_step_implicit."""
+        x = _d(x0).copy()
+        uu = _d(u_held) if u_held is not None else None
+        lib().orc_implicit(self.h, _p(x), t0, h, n_steps, n_iter, amp, duration, idx, _p(uu) if uu is not None else None)
         return x
 
     def rk4_impulse_batch(self, X0, dt, n_steps, amps, duration=0.01, idx=-2, t0=0.0, n_threads=0):

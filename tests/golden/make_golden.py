@@ -510,8 +510,70 @@ def g7_rk45():
     np.savez_compressed(os.path.join(HERE, "g7_rk45.npz"), **out)
 
 
+def g8_lsoda():
+    """scipy.integrate.solve_ivp(method="LSODA") over the reference RHS: the integration the reference's examples run
+    (examples/example_utilities.py:153-159: LSODA, default rtol 1e-3 / atol 1e-6, tip impulse 0.1 N for t < 0.01 s),
+    once at TIGHT tolerances (rtol 1e-10, atol 1e-13: the ODE's solution, what an implicit stepper must converge to)
+    and once at the example's own default tolerances (the band the example itself lands in).  Config 1 of
+    BASELINE.json (10 linear elements + gravity) and the 6-segment beams of the parallel examples."""
+    from scipy.integrate import solve_ivp
+
+    out = {}
+    half = 3
+    jobs = [
+        ("lin10_grav", nitinol(10, "linear"), dict(enable_gravity_effects=True), [0.02, 0.05, 0.1]),
+        ("lin6_fluid", nitinol(6, "linear"), dict(fluid_density=1000.0, enable_fluid_effects=True), [0.02, 0.05]),
+        ("mixed6_fluid", nitinol(6, ["linear"] * half + ["nonlinear"] * (6 - half)),
+         dict(fluid_density=1000.0, enable_fluid_effects=True), [0.02, 0.05]),
+    ]
+    for name, df, kw, times in jobs:
+        t_start = time.time()
+        out.update(fp_arrays(name, kw))
+        path = write_csv(df)
+        try:
+            beam = DynamicEulerBernoulliBeam(path, force_params=ForceParams(**kw))
+        finally:
+            os.unlink(path)
+        out.update(df_arrays(name, beam.params))
+        beam.create_system_func()
+        beam.create_input_func()
+        dyn = beam.get_dynamic_system()
+        n = beam.beam_model.M.shape[0]
+        amp, duration = 0.1, 0.01
+
+        def u_of_t(t, n=n):
+            u = np.zeros(n)
+            if t < duration:
+                u[-2] = amp
+            return u
+
+        def run(rtol, atol):
+            # (integrate piecewise over the impulse switch-off so that tight tolerances are meaningful there)
+            x, t0, ys, nfev = np.zeros(2 * n), 0.0, [], 0
+            for t1 in sorted(set([duration] + list(times))):
+                sol = solve_ivp(lambda t, x: dyn(t, x, u_of_t(0.5 * (t0 + t1))), (t0, t1), x, method="LSODA", rtol=rtol, atol=atol)
+                assert sol.success
+                x, t0, nfev = sol.y[:, -1], t1, nfev + sol.nfev
+                if t1 in times:
+                    ys.append(x.copy())
+            return np.array(ys), nfev
+
+        tight, nfev_t = run(1e-10, 1e-13)
+        loose, nfev_l = run(1e-3, 1e-6)
+        out[f"{name}/amp"], out[f"{name}/duration"] = np.float64(amp), np.float64(duration)
+        out[f"{name}/times"] = np.array(times)
+        out[f"{name}/x_tight"] = tight
+        out[f"{name}/x_default_tol"] = loose
+        out[f"{name}/nfev_tight"], out[f"{name}/nfev_default_tol"] = np.int64(nfev_t), np.int64(nfev_l)
+        print(f"G8 {name}: tip w(t_end) tight {tight[-1][n - 2]!r} / default tol {loose[-1][n - 2]!r}; nfev {nfev_t} / {nfev_l} "
+              f"({time.time() - t_start:.0f} s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "g8_lsoda.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8"]
+    if "g8" in which:
+        g8_lsoda()
     if "g7" in which:
         g7_rk45()
     if "g6" in which:

@@ -1284,3 +1284,69 @@ def test_batched_functional_composition_matches_oracle(n_e, kind):
     a.step_composed(12, dt, impulse_amp=amps)
     b2.step(12, dt, impulse_amp=amps)
     assert_blocks(a.unpack_state().cpu().numpy(), b2.unpack_state().cpu().numpy(), a.free_index, 1e-11)
+
+
+# ------------------------------------------------------------------ implicit stepper (stiff integrations, f-2)
+@pytest.mark.parametrize("n_e,kind,kw,h", [
+    (10, "linear", dict(enable_gravity=True), 1e-3),                                   # BASELINE config 1's beam
+    (6, "mixed", dict(fluid_density=1000.0, enable_fluid=True), 1e-4),                 # the parallel examples' mixed beam
+    (64, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), 2e-4),            # one wave per beam, 6 levels
+    (130, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True), 5e-4),   # 4 waves, padding threads
+    (256, "linear", dict(enable_gravity=True), 1e-3),                                  # 8 levels: the largest supported
+])
+def test_implicit_stepper_matches_oracle(n_e, kind, kw, h):
+    """crb_step_implicit (implicit midpoint rule, modified Newton with A = M + h^2/4 K0 by cyclic reduction) against
+    the oracle's dense-LU statement of the same scheme, per DOF block, at step sizes 5x .. 50x beyond the explicit
+    stability limit; chunked calls equal one call up to the restart of the iteration."""
+    half = n_e // 2
+    kinds = (["linear"] * half + ["nonlinear"] * (n_e - half)) if kind == "mixed" else kind
+    cols = nitinol_columns(n_e, kinds)
+    ob = oracle_beam(cols, **kw)
+    B, steps = 3, 40
+    amps = np.array([0.05, 0.1, 0.2])
+    rng = np.random.default_rng(n_e)
+    x0 = rng.normal(0.0, 1e-6, (B, 2 * ob.n))
+    dur = 10.0 * h          # the impulse switches off on a step boundary, inside the run
+    ens = ensemble(cols, B, kw)
+    ens.set_state(x0)
+    t = ens.step_implicit(steps, h, n_iter=3, impulse_amp=amps, impulse_duration=dur)
+    assert abs(t - steps * h) < 1e-12
+    got = ens.unpack_state().cpu().numpy()
+    for b in range(B):
+        want = ob.implicit(x0[b], h, steps, n_iter=3, amp=amps[b], duration=dur)
+        assert np.isfinite(want).all()
+        # cond(A) ~ 1e6..1e9 at these step sizes (alpha K0 dominates M): cyclic reduction and the oracle's dense LU
+        # round differently; the measured agreement is 1e-9..1e-8 per block
+        assert_blocks(got[b], want, ens.free_index, 1e-7, what=(n_e, b))
+    # held force + recording through the same entry point
+    ens.set_state(x0)
+    u = rng.normal(0.0, 1e-3, (B, ob.n))
+    _, rec = ens.step_implicit(20, h, n_iter=2, held_force=u, record=(n_e, "w"), record_every=5, t0=0.0)
+    assert rec.shape == (B, 4)
+    want = ob.implicit(x0[1], h, 20, n_iter=2, u_held=u[1])
+    assert_blocks(ens.unpack_state().cpu().numpy()[1], want, ens.free_index, 1e-7)
+    assert abs(float(rec[1, -1]) - want[ob.n - 2]) <= 1e-7 * abs(want[ob.n - 2])
+
+
+def test_implicit_stepper_integrates_config1_to_the_lsoda_golden(golden):
+    """BASELINE config 1 (10 linear elements + gravity, the reference's CPU example) integrated to t = 0.02 / 0.05 /
+    0.1 s in ONE launch each, against scipy LSODA (rtol 1e-10) over the REFERENCE RHS (tests/golden/g8_lsoda.npz,
+    anchor tip w(0.1) = -0.0725343890628583).  At h = 1e-4 s the tip displacement is within LSODA's DEFAULT tolerance
+    band (atol 1e-6 + rtol 1e-3 |w|, what the example itself asks of its integrator) at every time -- the error is
+    ~1e-6 m of unresolved high-frequency content, constant in time, so the relative figure falls as the beam deflects."""
+    z = golden["g8_lsoda"]
+    name = "lin10_grav"
+    ens = ensemble(beam_columns(z, name), 2, force_kwargs(z, name))
+    tight = z[f"{name}/x_tight"]
+    w_bound = {0.02: 1e-3, 0.05: 3e-4, 0.1: 6e-5}      # measured 3.8e-4, 9.4e-5, 1.9e-5 (w block, relative)
+    for k, t_end in enumerate(z[f"{name}/times"]):
+        ens.zero_state()
+        ens.step_implicit(int(round(t_end / 1e-4)), 1e-4, n_iter=2, impulse_amp=np.full(2, 0.1))
+        got = ens.unpack_state().cpu().numpy()
+        errs = block_errs(got[0], tight[k], ens.free_index)
+        assert errs["w"] < w_bound[round(float(t_end), 2)], (t_end, errs)
+        tip, ref = got[0, ens.n - 2], tight[k][ens.n - 2]
+        assert abs(tip - ref) < 1e-6 + 1e-3 * abs(ref), (t_end, tip, ref)       # LSODA's default tolerance band
+        assert abs(tip - ref) < 2e-6                                            # (measured 1.2e-6, 1.5e-6, 5.9e-7 m)
+        assert np.array_equal(got[0], got[1])
+    assert abs(got[0, ens.n - 2] / tight[-1][ens.n - 2] - 1.0) < 2e-5          # t = 0.1 s: 8e-6 relative
