@@ -349,8 +349,9 @@ def worker(args):
             events.append((e0, e1, k))
             done += k
         # the one exchange: RCCL all-gather of the terminal states in the reference's reduced ordering
-        # ([B, 2n], no padding lanes: 50 MB per rank for config 3); no-op at N = 1
-        gathered = gather_terminal_states(ens.unpack_state(), sizes=sizes)
+        # ([B, 2n], no padding lanes: 50 MB per rank for config 3).  One rank has nobody to exchange with: the
+        # states stay where they are (the layout conversion belongs to the exchange and is not run either)
+        gathered = gather_terminal_states(ens.unpack_state(), sizes=sizes) if dist else None
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -379,7 +380,7 @@ def worker(args):
     # ---- sanity / parity of what was just timed (after the clock stopped)
     state = ens.unpack_state()
     finite = bool(torch.isfinite(state).all())
-    check = {"finite": finite, "gathered_beams": int(gathered.shape[0])}
+    check = {"finite": finite, "gathered_beams": int(gathered.shape[0]) if gathered is not None else int(state.shape[0])}
     if rank == 0:
         b = B - 1
         ob = oracle_beam(params[b] if args.hetero else cols, **okw)

@@ -12,6 +12,8 @@ for f in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
         kname = k
         ndisp.add((f, row["Dispatch_Id"]))
         tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+# (round 2: a wave of the lean stepper walks over several beams, so SQ_WAVES is no longer "beams x waves per beam";
+#  profiles/r02_sq_*.json are normalised by beams x waves-per-beam x steps x 4 stages from the bench configuration)
 waves = tot.get("SQ_WAVES", 0.0)
 stages = 200 * 4
 res = {"tag": tag, "kernel": kname, "counters": tot,
