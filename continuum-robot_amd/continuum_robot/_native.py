@@ -109,6 +109,8 @@ def load():
     for name in ("crb_pack_state", "crb_unpack_state", "crb_pack_vec", "crb_unpack_vec", "crb_internal_force"):
         getattr(L, name).argtypes = [vp, vp, vp, vp]
     L.crb_rhs.argtypes = [vp, vp, vp, vp, vp]
+    L.crb_rhs_host.argtypes = [vp, _dp, _dp, _dp]
+    L.crb_internal_force_host.argtypes = [vp, _dp, _dp]
     L.crb_step_rk4.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), _dp, vp]
     L.crb_step_rk4_rec.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), C.POINTER(RecordDesc), _dp,
                                    vp]
@@ -257,6 +259,23 @@ class Plan:
                 self.h = None
         except Exception:
             pass
+
+    # ---- host-vector calls (single-beam closures): one launch + one synchronisation each
+    def rhs_host(self, x_red, u_red=None):
+        """xdot = [v ; Minv(-k(q) + f_drag + f_gravity + u)] for host vectors [n_beams, 2n] / [n_beams, n] (or 1-D for
+        one beam), in the reference's reduced ordering."""
+        x = np.ascontiguousarray(x_red, dtype=np.float64)
+        out = np.empty_like(x)
+        u = None if u_red is None else np.ascontiguousarray(u_red, dtype=np.float64)
+        check(load().crb_rhs_host(self.h, x.ctypes.data_as(_dp), u.ctypes.data_as(_dp) if u is not None else None,
+                                  out.ctypes.data_as(_dp)))
+        return out
+
+    def internal_force_host(self, q_red):
+        q = np.ascontiguousarray(q_red, dtype=np.float64)
+        out = np.empty_like(q)
+        check(load().crb_internal_force_host(self.h, q.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+        return out
 
     # ---- inspection (host)
     def mass(self):

@@ -145,7 +145,7 @@ class DynamicEulerBernoulliBeam:
             self._fused[key] = BeamEnsemble(self.params, 1, force_params=fp)
         return self._fused[key]
 
-    def _registry_rhs(self, x: np.ndarray) -> np.ndarray:
+    def _registry_rhs(self, x: np.ndarray, u: np.ndarray = None) -> np.ndarray:
         """system(x) of the registry-based default: enabled auto-registered drag / gravity are lowered to
         the kernel's fused force terms, every other registered force is a Python callable summed on the
         host (force time argument 0.0, reference :265)."""
@@ -160,6 +160,8 @@ class DynamicEulerBernoulliBeam:
             else:
                 part = np.asarray(force.compute_forces(x, 0.0), dtype=np.float64)
                 extra = part.copy() if extra is None else extra + part
+        if u is not None:
+            extra = np.asarray(u, dtype=np.float64) if extra is None else extra + u
         ens = self._fused_ensemble(drag_on, gravity)
         n = ens.n
         x = np.asarray(x, dtype=np.float64)
@@ -167,7 +169,8 @@ class DynamicEulerBernoulliBeam:
             raise ValueError(f"State vector length {x.shape} must be {2 * n}")
         if extra is not None and extra.shape != (n,):
             raise ValueError(f"dimension mismatch: force vector of length {extra.shape} for {n} position DOFs")
-        return ens.rhs(x.reshape(1, -1), None if extra is None else extra.reshape(1, -1)).cpu().numpy()[0]
+        # one launch on host vectors (crb_rhs_host): the closures are called ~6e5 times per simulated second by LSODA
+        return ens.plan.rhs_host(x, extra)
 
     def _structural_rhs(self, x: np.ndarray, generalized_force: np.ndarray) -> np.ndarray:
         """[v ; Minv(-k(q) + force)] by one launch of the RHS kernel (one beam)."""
@@ -179,7 +182,7 @@ class DynamicEulerBernoulliBeam:
             raise ValueError(f"State vector length {x.shape} must be {2 * n}")
         if force.ndim != 1 or force.shape[0] != n:
             raise ValueError(f"dimension mismatch: force vector of length {force.shape} for {n} position DOFs")
-        return ens.rhs(x.reshape(1, -1), force.reshape(1, -1)).cpu().numpy()[0]
+        return ens.plan.rhs_host(x, force)
 
     def to_ensemble(self, n_beams: int, **kwargs):
         """The fused batched stepper for this model (drag / gravity inside the kernel)."""
@@ -232,5 +235,28 @@ class DynamicEulerBernoulliBeam:
         def dynamic_system(t: float, x: np.ndarray, u: Union[np.ndarray, Callable]) -> np.ndarray:
             force = u(t) if callable(u) else u
             return self.system_func(x) + self.input_func(x, force, t)
+
+        return dynamic_system
+
+    def get_fused_dynamic_system(self) -> Callable:
+        """``dynamic_system(t, x, u)`` with the registry forces AND the input in ONE right-hand side launch:
+        [v ; Minv(-k(q) + f(x, 0) + u)] -- the sum ``system(x) + input(x, u, t)`` of get_dynamic_system() with a
+        single mass solve (rounding-level difference, one launch instead of two per call).  Same argument checks."""
+        if self.system_func is None or self.input_func is None:
+            raise RuntimeError("System and input functions must be created first")
+        if self.system_func != self._registry_rhs:
+            return self.get_dynamic_system()      # a user forces_func: keep the two-call composition
+
+        def dynamic_system(t: float, x: np.ndarray, u: Union[np.ndarray, Callable]) -> np.ndarray:
+            force = u(t) if callable(u) else u
+            if not isinstance(x, np.ndarray) or not isinstance(force, np.ndarray):
+                raise ValueError("State and input must be numpy arrays")
+            if x.ndim != 1 or force.ndim != 1:
+                raise ValueError("State and input must be 1D arrays")
+            n = len(x) // 2
+            if len(force) != n:
+                raise ValueError(
+                    f"Input vector length {len(force)} must match position DOFs {n}. Expected {n}, got {len(force)}")
+            return self._registry_rhs(x, force)
 
         return dynamic_system

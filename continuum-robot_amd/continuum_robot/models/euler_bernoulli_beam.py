@@ -122,8 +122,10 @@ class EulerBernoulliBeam(IBeam):
 
         def global_stiffness_function(x: np.ndarray) -> np.ndarray:
             ens = self._device_ensemble()
-            q = np.asarray(x, dtype=np.float64).reshape(1, -1)
-            return ens.internal_force(q).cpu().numpy()[0]
+            q = np.asarray(x, dtype=np.float64)
+            if q.shape != (ens.n,):
+                raise ValueError(f"expected shape {(ens.n,)}, got {q.shape}")
+            return ens.plan.internal_force_host(q)    # one launch on host vectors (crb_internal_force_host)
 
         return global_stiffness_function
 

@@ -76,6 +76,11 @@ struct KParams {
     int n_steps;
     T gx, gy;
     const T* gvec;             // [B][2] per-beam gravity vector (mixed ensembles), or nullptr: gx, gy for every beam
+    // reduced I/O (MODE_RHS / MODE_KQ, crb_rhs_host): when red_map != nullptr, x / u_held / out are vectors in the
+    // reference's REDUCED ordering ([B][2 n_red] states, [B][n_red] forces) and red_map[3 node + dof] is the reduced
+    // index of a DOF or -1 -- the (un)packing of crb_pack_* fused into the kernel's own loads and stores
+    const int32_t* red_map;
+    int n_red;
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
@@ -333,7 +338,19 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
     T x[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
     T uh[3] = {T(0), T(0), T(0)};
     T amp = T(0);
-    if (valid) {
+    int red[3] = {-1, -1, -1};   // reduced indices of this node's DOFs (reduced I/O only)
+    if (valid && (MODE == MODE_RHS || MODE == MODE_KQ) && p.red_map) {
+        const size_t rb = size_t(beam) * 2 * size_t(p.n_red), ub = size_t(beam) * size_t(p.n_red);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            red[c] = p.red_map[3 * node + c];
+            if (red[c] >= 0) {
+                x[c] = p.x[rb + red[c]];
+                if (MODE == MODE_RHS) x[3 + c] = p.x[rb + p.n_red + red[c]];
+                if (p.u_held) uh[c] = p.u_held[ub + red[c]];
+            }
+        }
+    } else if (valid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             x[c] = p.x[xoff + c] * sc.mask[c];
@@ -387,7 +404,15 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
     if (MODE != MODE_STEP) {
         T a[3];
         stage_accel<T, LV, MODE == MODE_KQ, LEAN>(p, lds, sc, cf, tp, x, x + 3, uh, a);
-        if (valid) {
+        if (valid && p.red_map) {
+            const size_t rb = size_t(beam) * (MODE == MODE_KQ ? 1 : 2) * size_t(p.n_red);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (red[c] >= 0) {
+                    if (MODE == MODE_KQ) p.out[rb + red[c]] = a[c];
+                    else { p.out[rb + red[c]] = x[3 + c]; p.out[rb + p.n_red + red[c]] = a[c]; }
+                }
+        } else if (valid) {
             if (MODE == MODE_KQ) {
                 const size_t ooff = size_t(beam) * plane + node * 4;
 #pragma unroll

@@ -74,6 +74,11 @@ struct crb_plan {
     mutable void* d_alevels = nullptr;   // [nd][levels_full][S][10]
     mutable void* d_afinal = nullptr;    // [nd][S][6]
     mutable double stiff_alpha = 0.0;    // alpha the tables above were built for (0 = none yet)
+    // host-vector entry points (crb_rhs_host): full -> reduced map on the device, pinned staging, a stream of the plan's own
+    mutable int32_t* d_red_map = nullptr;
+    mutable double* h_stage = nullptr;   // pinned + mapped: [2n | n | 2n] doubles (x, u, out)
+    mutable double* d_stage = nullptr;   // the device's view of h_stage
+    mutable hipStream_t host_stream = nullptr;
     int32_t* d_n_state = nullptr;     // [B] 2 * n_free_b, or null
     std::vector<double> h_levels, h_final, h_norms, h_mass, h_stiff;
     int first_nonlinear = -1;
@@ -667,6 +672,9 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         (void)hipFree(p->d_n_state);
         (void)hipFree(p->d_alevels);
         (void)hipFree(p->d_afinal);
+        (void)hipFree(p->d_red_map);
+        if (p->h_stage) (void)hipHostFree(p->h_stage);
+        if (p->host_stream) (void)hipStreamDestroy(p->host_stream);
         delete p->asm_in;
     }
     delete p;
@@ -1048,6 +1056,59 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     k.rec_out = static_cast<float*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
     if (lean_eligible(p, held)) return launch_lean<float>(p, k, st);
     return launch_beam<float, MODE_STEP>(p, k, st);
+}
+
+// ------------------------------------------------------------------ host-vector entry points (single-beam closures)
+namespace {
+int host_path_setup(const crb_plan* p, const char* who) {
+    if (int rc = need_device(p, who)) return rc;
+    if (p->dtype != CRB_F64) return fail(CRB_EUNSUPPORTED, std::string(who) + ": host-vector calls need an fp64 plan");
+    if (p->mixed_topology) return fail(CRB_EUNSUPPORTED, std::string(who) + ": host-vector calls need one free-DOF set for the plan");
+    if (p->d_red_map) return CRB_OK;
+    const size_t n = p->free_index.size();
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_red_map), p->full2red.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_red_map, p->full2red.data(), p->full2red.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_stage), size_t(p->B) * 5 * n * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_stage), p->h_stage, 0));
+    HIP_TRY(hipStreamCreateWithFlags(&p->host_stream, hipStreamNonBlocking));
+    return CRB_OK;
+}
+}  // namespace
+
+extern "C" int crb_rhs_host(const crb_plan* p, const double* x_red, const double* u_red, double* xdot_red) {
+    if (int rc = host_path_setup(p, "crb_rhs_host")) return rc;
+    if (!x_red || !xdot_red) return fail(CRB_EINVAL, "crb_rhs_host: null pointer");
+    const size_t n = p->free_index.size(), B = size_t(p->B);
+    double *hx = p->h_stage, *hu = hx + B * 2 * n, *ho = hu + B * n;
+    std::memcpy(hx, x_red, B * 2 * n * sizeof(double));
+    if (u_red) std::memcpy(hu, u_red, B * n * sizeof(double));
+    KParams<double> k = base_params<double>(p);
+    k.x = p->d_stage;
+    k.u_held = u_red ? p->d_stage + B * 2 * n : nullptr;
+    k.out = p->d_stage + B * 3 * n;
+    k.red_map = p->d_red_map;
+    k.n_red = int(n);
+    if (int rc = launch_beam<double, MODE_RHS>(p, k, p->host_stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(p->host_stream));
+    std::memcpy(xdot_red, ho, B * 2 * n * sizeof(double));
+    return CRB_OK;
+}
+
+extern "C" int crb_internal_force_host(const crb_plan* p, const double* q_red, double* k_red) {
+    if (int rc = host_path_setup(p, "crb_internal_force_host")) return rc;
+    if (!q_red || !k_red) return fail(CRB_EINVAL, "crb_internal_force_host: null pointer");
+    const size_t n = p->free_index.size(), B = size_t(p->B);
+    double *hx = p->h_stage, *ho = hx + B * 3 * n;
+    for (size_t b = 0; b < B; ++b) std::memcpy(hx + b * 2 * n, q_red + b * n, n * sizeof(double));   // (state rows of 2n: q | unused)
+    KParams<double> k = base_params<double>(p);
+    k.x = p->d_stage;
+    k.out = p->d_stage + B * 3 * n;
+    k.red_map = p->d_red_map;
+    k.n_red = int(n);
+    if (int rc = launch_beam<double, MODE_KQ>(p, k, p->host_stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(p->host_stream));
+    std::memcpy(k_red, ho, B * n * sizeof(double));
+    return CRB_OK;
 }
 
 // ------------------------------------------------------------------ implicit stepper (crb_stiff.h)

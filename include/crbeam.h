@@ -181,6 +181,16 @@ int crb_internal_force(const crb_plan* plan, const void* x, void* k, void* strea
  * (dynamic_beam_model.py:256-272, 294-328, 343-362).  u: device [B][n_node][4] or NULL. */
 int crb_rhs(const crb_plan* plan, const void* x, const void* u, void* xdot, void* stream);
 
+/* The same two functions for HOST vectors in the reference's reduced ordering, synchronously: what the single-beam
+ * closures handed to scipy.solve_ivp call (get_dynamic_system()(t, x, u), dynamic_beam_model.py:343-362;
+ * get_stiffness_function(), euler_bernoulli_beam.py:364-368) -- 6e5 calls per simulated second under LSODA.  The
+ * (un)packing is fused into the kernel's own loads and stores, the vectors travel through pinned, device-mapped
+ * staging of the plan: ONE launch + one stream synchronisation per call (the device-pointer forms above need
+ * pack + kernel + unpack + copies).  x_red / xdot_red: [n_beams][2 n_free], u_red: [n_beams][n_free] or NULL,
+ * q_red / k_red: [n_beams][n_free].  fp64 plans with one free-DOF set; not thread-safe per plan. */
+int crb_rhs_host(const crb_plan* plan, const double* x_red, const double* u_red, double* xdot_red);
+int crb_internal_force_host(const crb_plan* plan, const double* q_red, double* k_red);
+
 /* n_steps classical RK4 steps of size dt, in place, in ONE launch (replaces the
  * scipy.solve_ivp call sites example_utilities.py:153-159, lqr_control.py:117-125).  The clock
  * starts at t0 and accumulates by addition (t <- t + dt); stage times t, t+dt/2, t+dt.

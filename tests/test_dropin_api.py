@@ -545,3 +545,55 @@ def test_fused_registry_path_equals_host_composed_path_and_follows_runtime_chang
     fused.force_registry.register(MockForce(n, 0.5))   # a user force joins the fused built-ins
     hosted.force_registry.register(MockForce(n, 0.5))
     same()
+
+
+@gpu
+def test_host_vector_calls_equal_the_device_pointer_calls(golden):
+    """crb_rhs_host / crb_internal_force_host (reduced host vectors through pinned staging, (un)packing fused into
+    the RHS kernel: one launch per call) against the pack -> kernel -> unpack path, bit for bit, for beams with
+    constrained interior nodes and for several beams per plan; the closures of the drop-in classes go through them."""
+    from continuum_robot.batched import BeamEnsemble
+    from continuum_robot.models.force_params import ForceParams
+
+    z = golden["g34_forces_rhs"]
+    for bname, fname in (("hetero7_pinned0_fixed3", "both_xy"), ("test4_nl", "drag"), ("mixed5_fixed0_pinned2", "grav")):
+        key = f"{bname}/{fname}"
+        kw = force_kwargs(z, key)
+        fp = ForceParams(fluid_density=kw["fluid_density"], enable_fluid_effects=kw["enable_fluid"],
+                         gravity_vector=list(kw["gravity"]), enable_gravity_effects=kw["enable_gravity"])
+        X, U, ref = z[f"{key}/x"], z[f"{key}/u"], z[f"{key}/xdot"]
+        B = X.shape[0]
+        ens = BeamEnsemble(beam_columns(z, bname), B, force_params=fp)
+        us = np.stack([U[i % U.shape[0]] for i in range(B)])
+        want = ens.rhs(X, us).cpu().numpy()
+        got = ens.plan.rhs_host(X, us)
+        assert np.array_equal(got, want)
+        assert np.array_equal(ens.plan.rhs_host(X), ens.rhs(X).cpu().numpy())
+        n = ens.n
+        assert np.array_equal(ens.plan.internal_force_host(X[:, :n]), ens.internal_force(X[:, :n]).cpu().numpy())
+        for i in range(B):
+            assert_blocks(got[i], ref[i, i % U.shape[0]], ens.free_index, 1e-10)
+
+
+@gpu
+def test_fused_dynamic_system_equals_the_two_call_composition(beam_files):
+    """get_fused_dynamic_system(): registry forces and the input in ONE launch; equal to system(x) + input(x, u, t)
+    up to the rounding of one mass solve instead of two, same argument checks; a user forces_func keeps the
+    two-call form."""
+    from continuum_robot.models.dynamic_beam_model import DynamicEulerBernoulliBeam
+    from continuum_robot.models.force_params import ForceParams
+
+    beam = DynamicEulerBernoulliBeam(beam_files[1], force_params=ForceParams(fluid_density=1000.0, enable_fluid_effects=True,
+                                                                             enable_gravity_effects=True))
+    beam.create_system_func()
+    beam.create_input_func()
+    two, one = beam.get_dynamic_system(), beam.get_fused_dynamic_system()
+    n = beam.beam_model.M.shape[0]
+    rng = np.random.default_rng(8)
+    x, u = rng.normal(0, 1e-2, 2 * n), rng.normal(0, 1.0, n)
+    assert_blocks(one(0.1, x, u), two(0.1, x, u), _free_index(beam), 1e-12)
+    assert_blocks(one(0.1, x, lambda t: u * t), two(0.1, x, lambda t: u * t), _free_index(beam), 1e-12)
+    with pytest.raises(ValueError, match="must match position DOFs"):
+        one(0.0, x, np.zeros(n + 1))
+    beam.create_system_func(lambda x, t: np.zeros(n))
+    assert beam.get_fused_dynamic_system()(0.0, x, u).shape == (2 * n,)
