@@ -46,6 +46,14 @@ def test_launch_without_device_fails_loudly():
         nat.check(nat.load().crb_rhs(plan.h, C.c_void_p(8), None, C.c_void_p(16), None))
     with pytest.raises(nat.NativeError):
         nat.Plan(nitinol_columns(4), device=0 if not _has_gpu() else 99)
+    # the round-2 entry points refuse a host-only plan the same way (there is no CPU path behind any of them)
+    with pytest.raises(nat.NativeError, match="no CPU path"):
+        nat.check(nat.load().crb_step_implicit(plan.h, C.c_void_p(8), 0.0, 1e-3, 1, 2, None, None, None, None))
+    with pytest.raises(nat.NativeError, match="no CPU path"):
+        plan.rhs_host(np.zeros(2 * plan.n_free))
+    with pytest.raises(nat.NativeError, match="no CPU path"):
+        plan.internal_force_host(np.zeros(plan.n_free))
+    assert plan.beam_info(0) == (4, plan.n_free) and np.array_equal(plan.beam_free_index(0), plan.free_index)
 
 
 def _has_gpu():
