@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--launch-steps", type=int, default=None,
                     help="RK4 steps fused per launch (0 = all of --steps); warmup uses launches of the same size, so "
                          "every stepper launch of a run is identical and rocprof's per-kernel average is the launch time")
+    ap.add_argument("--gather-chunks", type=int, default=0,
+                    help="N > 1: split each rank's shard into this many chunks and all-gather chunk c asynchronously while "
+                         "chunk c+1 is stepped (0 = 4 when the shard allows it, 1 = one blocking exchange at the end)")
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed repeats of the K-step rollout (0 = as many as a 50 ms timed region needs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -270,40 +273,68 @@ def worker(args):
             c["moment_inertia"] = cols["moment_inertia"] * sr**4
             c["wetted_area"] = cols["wetted_area"] * sr
             params.append(c)
+    # N > 1: the shard is stepped in chunks so that the exchange of chunk c overlaps the stepping of chunk c + 1
+    # (continuum_robot.distributed.rollout_and_gather); every chunk is an ensemble of its own.  One rank: one ensemble.
+    n_chunks = 1
+    if dist and not cfg.get("lqr") and not cfg.get("implicit") and not args.hetero and min(sizes) == max(sizes):
+        want = args.gather_chunks
+        if want == 0:
+            # chunk only when the exchange is a visible share of the rollout (a rule every rank evaluates identically):
+            # one shard travels to each peer over its own xGMI link (~60 GB/s effective assumed, + 50 us of launch
+            # latency) against the stepping time at the nominal single-GPU rate.  20 steps: 0.9 ms of exchange next to
+            # 0.6 ms of stepping -> 4 chunks; 1000 steps: 3 % -> one blocking exchange (chunking costs ~3 % by itself)
+            shard_bytes = B * 2 * 3 * ne * (8 if args.dtype == "f64" else 4)
+            est_exchange = shard_bytes / 60e9 + 50e-6
+            est_stepping = B * ne * args.steps / (3.7e10 if args.dtype == "f64" else 7.5e10)
+            want = 4 if est_exchange > 0.15 * est_stepping else 1
+        while want > 1 and (B % want or B // want < 512):
+            want -= 1
+        n_chunks = max(1, want)
+    Bc = B // n_chunks
     t_plan = time.perf_counter()
-    ens = BeamEnsemble(params, B, force_params=fp, dtype=dtype, device=f"cuda:{local_rank}")
+    enss = [BeamEnsemble(params if not args.hetero else params[c * Bc:(c + 1) * Bc], Bc, force_params=fp, dtype=dtype,
+                         device=f"cuda:{local_rank}") for c in range(n_chunks)]
+    ens = enss[0]
     torch.cuda.synchronize()
     plan_ms = (time.perf_counter() - t_plan) * 1e3
 
     amps = torch.as_tensor(impulse_amplitudes(B_total, lo, hi, cfg.get("amp", 0.1)), dtype=dtype, device=ens.device)
+    amps_c = [amps[c * Bc:(c + 1) * Bc].contiguous() for c in range(n_chunks)]
     gain = None
     if cfg.get("lqr"):
         t_gain = time.perf_counter()
         gain = torch.as_tensor(lqr_gain(ens), dtype=dtype, device=ens.device)
         print(f"[bench] LQR gain {tuple(gain.shape)} solved in {time.perf_counter() - t_gain:.1f} s", file=sys.stderr)
-    x0 = x0n = None
+    x0n = None
+    x0_c = [None] * n_chunks
     if cfg["x0"]:
         x0n = initial_states(lo, hi, ens.n)
-        x0 = ens.pack_state(x0n)
+        x0_c = [enss[c].pack_state(x0n[c * Bc:(c + 1) * Bc]) for c in range(n_chunks)]
 
     def reset():
-        if x0 is None:
-            ens.zero_state()
-        else:
-            ens.state.copy_(x0)
-            ens.time = 0.0
+        for e, x0 in zip(enss, x0_c):
+            if x0 is None:
+                e.zero_state()
+            else:
+                e.state.copy_(x0)
+                e.time = 0.0
 
     dt = cfg.get("dt", 2e-5)
     per_launch = args.launch_steps if args.launch_steps > 0 else args.steps
     per_launch = min(per_launch, args.steps)
 
-    def advance(k):
+    def advance_one(c, k):
+        e = enss[c]
         if cfg.get("implicit"):
-            ens.step_implicit(k, dt, n_iter=2, impulse_amp=amps)
+            e.step_implicit(k, dt, n_iter=2, impulse_amp=amps_c[c])
         elif gain is None:
-            ens.step(k, dt, impulse_amp=amps)
+            e.step(k, dt, impulse_amp=amps_c[c])
         else:
-            ens.step_feedback(k, dt, gain, impulse_amp=amps)
+            e.step_feedback(k, dt, gain, impulse_amp=amps_c[c])
+
+    def advance(k):
+        for c in range(n_chunks):
+            advance_one(c, k)
 
     # ---- warmup (untimed), then restore the initial state so the timed K steps are the
     # parity-checked trajectory (the shipped nonlinear element is only stable to ~1000 steps)
@@ -324,7 +355,12 @@ def worker(args):
     if dist:
         # warm the collective path too (RCCL builds its communicator / channels lazily on first use:
         # tens of ms that do not belong to the timed steps)
-        gather_terminal_states(ens.unpack_state(), sizes=sizes)
+        from continuum_robot.distributed import assemble_chunks, rollout_and_gather
+
+        if n_chunks > 1:
+            rollout_and_gather(enss, lambda e: None)
+        else:
+            gather_terminal_states(ens.unpack_state(), sizes=sizes)
         warm = torch.zeros(1, dtype=torch.float64, device=ens.device)
         dist.all_reduce(warm, op=dist.ReduceOp.MAX)
         dist.barrier()
@@ -339,19 +375,28 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
-        done = 0
-        while done < args.steps:
-            k = min(per_launch, args.steps - done)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()   # (the stepper launches on torch's current stream: BeamEnsemble._stream)
-            advance(k)
-            e1.record()
-            events.append((e0, e1, k))
-            done += k
+
+        def rollout(c):   # all launches of one chunk (the whole shard when it is not chunked)
+            done = 0
+            while done < args.steps:
+                k = min(per_launch, args.steps - done)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()   # (the stepper launches on torch's current stream: BeamEnsemble._stream)
+                advance_one(c, k)
+                e1.record()
+                events.append((e0, e1, k))
+                done += k
+
         # the one exchange: RCCL all-gather of the terminal states in the reference's reduced ordering
         # ([B, 2n], no padding lanes: 50 MB per rank for config 3).  One rank has nobody to exchange with: the
-        # states stay where they are (the layout conversion belongs to the exchange and is not run either)
-        gathered = gather_terminal_states(ens.unpack_state(), sizes=sizes) if dist else None
+        # states stay where they are (the layout conversion belongs to the exchange and is not run either).
+        # With chunks the exchange of chunk c runs on RCCL's stream while chunk c + 1 is stepped.
+        if n_chunks > 1:
+            index = {id(e): c for c, e in enumerate(enss)}
+            gathered = rollout_and_gather(enss, lambda e: rollout(index[id(e)]))
+        else:
+            rollout(0)
+            gathered = gather_terminal_states(ens.unpack_state(), sizes=sizes) if dist else None
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -378,13 +423,16 @@ def worker(args):
     avg_launch_s = float(np.mean(full)) * 1e-3
 
     # ---- sanity / parity of what was just timed (after the clock stopped)
-    state = ens.unpack_state()
+    state = torch.cat([e.unpack_state() for e in enss], dim=0) if n_chunks > 1 else ens.unpack_state()
     finite = bool(torch.isfinite(state).all())
+    if isinstance(gathered, list):     # chunked exchange: back to global beam order, and it must equal what this rank holds
+        gathered = assemble_chunks(gathered, world)
+        assert torch.equal(gathered[lo:hi], state), "chunked all-gather does not reproduce this rank's states"
     check = {"finite": finite, "gathered_beams": int(gathered.shape[0]) if gathered is not None else int(state.shape[0])}
     if rank == 0:
         b = B - 1
         ob = oracle_beam(params[b] if args.hetero else cols, **okw)
-        x0b = np.zeros(2 * ob.n) if x0 is None else x0n[b]
+        x0b = np.zeros(2 * ob.n) if x0n is None else x0n[b]
         if cfg.get("implicit"):
             ref = ob.implicit(x0b, dt, args.steps, n_iter=2, amp=float(amps[b].item()))
             check["simulated_seconds"] = args.steps * dt
@@ -407,7 +455,7 @@ def worker(args):
             check["oracle_block_sensitivity_4ulp"] = rollout_conditioning(ob, x0b, dt, args.steps, float(amps[b].item()))
         check["tip_w_last_beam"] = float(state[b, ens.n - 2].item())
         if args.verify_all and gain is None and not args.hetero:
-            X0 = np.zeros((B, 2 * ob.n)) if x0 is None else x0n
+            X0 = np.zeros((B, 2 * ob.n)) if x0n is None else x0n
             ref_all, _ = ob.rk4_impulse_batch(X0, dt, args.steps, amps.double().cpu().numpy())
             got_all = state.double().cpu().numpy()
             errs = np.linalg.norm(got_all - ref_all, axis=1) / np.maximum(np.linalg.norm(ref_all, axis=1), 1e-300)
@@ -417,7 +465,7 @@ def worker(args):
 
     # ---- roofline of the dominant kernel
     if gain is None:
-        algo_bytes_launch = BYTES_PER_ELEM_STEP[args.dtype] * B * ne * per_launch
+        algo_bytes_launch = BYTES_PER_ELEM_STEP[args.dtype] * Bc * ne * per_launch   # (per launch: one chunk's beams)
         achieved = algo_bytes_launch / avg_launch_s / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -492,13 +540,16 @@ def worker(args):
                        "launched_by": "bench.py launcher" if os.environ.get("CRB_BENCH_LAUNCHED") else
                                       ("external launcher" if "WORLD_SIZE" in os.environ else "single process"),
                        "collective": ("all_gather_into_tensor(terminal states [B,2n]" +
-                                      (", padded to the largest shard)" if min(sizes) != max(sizes) else ")")) if dist else "none",
+                                      (", padded to the largest shard)" if min(sizes) != max(sizes) else ")") +
+                                      (f" in {n_chunks} chunks, chunk c overlapped with the stepping of chunk c+1" if n_chunks > 1 else ""))
+                                     if dist else "none",
+                       "gather_chunks": n_chunks,
                        "plan_ms": plan_ms},
             "roofline": roofline,
             "check": check,
         }
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file) and world == 1:
+        if os.path.exists(traffic_file) and world == 1 and n_chunks == 1:
             try:
                 tj = json.load(open(traffic_file))
                 # HBM traffic of a stepper launch is one read + one write of the state, whatever the number of fused
@@ -510,7 +561,7 @@ def worker(args):
                     if "valu_instr_per_elem_step" in tj[key] and gain is None:
                         # the limiter that actually binds: vector-ALU issue slots (one wave instruction per
                         # SIMD every 4 cycles, 1024 SIMDs, nominal 2.4 GHz), instruction count from the PMC run
-                        lane_instr = tj[key]["valu_instr_per_elem_step"] * B * ne * per_launch / avg_launch_s
+                        lane_instr = tj[key]["valu_instr_per_elem_step"] * Bc * ne * per_launch / avg_launch_s
                         out["roofline"]["valu_issue_frac"] = lane_instr / (1024 * 64 * VALU_CLOCK_HZ / 4)
                         out["roofline"]["valu_source"] = tj[key].get("valu_source")
             except Exception as e:  # a malformed side file must not cost the run its result line

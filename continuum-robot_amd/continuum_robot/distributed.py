@@ -71,3 +71,42 @@ def gather_terminal_states(local: torch.Tensor, group=None, sizes: Optional[Sequ
     out = torch.empty((world * biggest,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * biggest:r * biggest + sizes[r]] for r in range(world)], dim=0)
+
+
+def rollout_and_gather(chunks, advance, group=None):
+    """Step an ensemble that was split into ``chunks`` (a list of BeamEnsemble-like objects: consecutive, equally sized
+    blocks of this rank's beams) and all-gather every chunk's terminal states WHILE the next chunk is being stepped.
+
+    ``advance(ens)`` enqueues the whole rollout of one chunk on the current stream.  After each chunk its states are
+    converted to the reference's reduced ordering and handed to an asynchronous ``all_gather_into_tensor``
+    (``async_op=True``: with nccl the RCCL kernels run on the process group's own stream, ordered after the chunk's
+    stepper by an event) -- so on N > 1 GPUs only the LAST chunk's exchange is exposed: a rollout of a few dozen steps
+    is as short as the all-gather of its result (20 steps of 4096 x 256: 0.6 ms; 8 x 50 MB over xGMI: ~0.5 ms).
+    Every rank must hold the same number of rows per chunk.  Returns the list of gathered tensors, one per chunk,
+    each ``[world * rows_per_chunk, ...]`` in rank order (``assemble_chunks`` restores the global beam order);
+    without an initialised process group the chunks' own states are returned.
+    """
+    outs, works, keep = [], [], []
+    on = dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    for ens in chunks:
+        advance(ens)
+        red = ens.unpack_state().contiguous()
+        if on:
+            out = torch.empty((world * red.shape[0],) + tuple(red.shape[1:]), dtype=red.dtype, device=red.device)
+            works.append(dist.all_gather_into_tensor(out, red, group=group, async_op=True))
+            keep.append(red)      # the send buffer must outlive the collective
+            outs.append(out)
+        else:
+            outs.append(red)
+    for w in works:
+        w.wait()                  # the current stream now waits for every exchange
+    return outs
+
+
+def assemble_chunks(outs, world: int) -> torch.Tensor:
+    """``rollout_and_gather``'s per-chunk results -> one tensor in GLOBAL beam order (rank-major, then chunk, then row)."""
+    if len(outs) == 1:
+        return outs[0]
+    per = [o.reshape((world, o.shape[0] // world) + tuple(o.shape[1:])) for o in outs]
+    return torch.cat(per, dim=1).reshape((-1,) + tuple(outs[0].shape[1:]))

@@ -160,3 +160,55 @@ def test_bench_initial_states_do_not_depend_on_the_world_size():
     a = bench.parse(["--gpus", "8", "--config", "config5", "--scaling", "strong"])
     assert a.steps == 1000 and a.scaling == "strong" and a.dtype == "f64"
     assert bench.parse(["--config", "config4"]).scaling == "strong" and bench.parse([]).scaling == "weak"
+
+
+
+class _FakeChunk:
+    """stands in for a BeamEnsemble chunk on the CPU: 'stepping' adds 1 to its rows"""
+
+    def __init__(self, rows):
+        self.x = rows.clone()
+
+    def unpack_state(self):
+        return self.x
+
+
+def _worker_chunked(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from continuum_robot.distributed import assemble_chunks, rollout_and_gather, shard_range
+
+        total, n_chunks = 24, 3
+        lo, hi = shard_range(total, world, rank)
+        rows = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1).repeat(1, 4)
+        per = (hi - lo) // n_chunks
+        chunks = [_FakeChunk(rows[c * per:(c + 1) * per]) for c in range(n_chunks)]
+        stepped = []
+
+        def advance(ens):
+            ens.x = ens.x + 1.0
+            stepped.append(ens)
+
+        outs = rollout_and_gather(chunks, advance)
+        assert len(outs) == n_chunks and stepped == chunks
+        full = assemble_chunks(outs, world)
+        assert full.shape == (total, 4)
+        assert torch.equal(full[:, 2], torch.arange(total, dtype=torch.float64) + 1.0)   # global beam order, every chunk stepped
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_rollout_with_overlapped_allgather(tmp_path):
+    """rollout_and_gather: per-chunk asynchronous all-gathers (the exchange of chunk c runs while chunk c + 1 is
+    stepped) and the reassembly into global beam order, on two gloo ranks."""
+    world = 2
+    mp.spawn(_worker_chunked, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+    # without a process group the chunks come back as they are
+    from continuum_robot.distributed import assemble_chunks, rollout_and_gather
+
+    chunks = [_FakeChunk(torch.full((2, 3), float(c))) for c in range(3)]
+    outs = rollout_and_gather(chunks, lambda e: None)
+    assert torch.equal(assemble_chunks(outs, 1)[:, 0], torch.tensor([0.0, 0, 1, 1, 2, 2]))
