@@ -263,6 +263,25 @@ class BeamEnsemble:
         """[n_rec, B, 2, n_node, 4] snapshots of step(..., record="all") -> reduced [n_rec, B, 2n] (sol.y ordering)."""
         return torch.stack([self.unpack_state(snaps[k]) for k in range(snaps.shape[0])])
 
+    def beam_shapes(self, snaps: torch.Tensor, dx: float, as_reference: bool = True):
+        """Beam x, y coordinates over time from whole-state snapshots (``step(..., record="all")`` /
+        ``solve_rk45(record="all")`` / ``step_implicit(record="all")``), the reference's
+        ``extract_beam_shapes(sol, n_segments, dx)`` (examples/example_utilities.py:173-205) for every beam:
+        x[t, b, j] = j * dx, y[t, b, 0] = 0 (fixed base), y[t, b, j + 1] = pos[j].
+
+        ``as_reference=True`` reproduces the reference's indexing ``pos = sol.y[n_pos + 1::3]`` -- entries of the
+        VELOCITY half of the state (the transverse RATES dw/dt of the free nodes, not the
+        displacements); ``False`` reads the transverse displacements ``sol.y[1:n_pos:3]`` the docstring there means.
+        Returns numpy arrays of shape [n_t, B, n_elem + 1]."""
+        red = self.unpack_snapshots(snaps).detach().cpu().numpy()        # [n_t, B, 2n]: sol.y per beam, transposed
+        n_t, n_pts = red.shape[0], self.n_elem + 1
+        x = np.broadcast_to(np.arange(n_pts) * float(dx), (n_t, self.n_beams, n_pts)).copy()
+        y = np.zeros((n_t, self.n_beams, n_pts))
+        pos = red[:, :, self.n + 1::3] if as_reference else red[:, :, 1:self.n:3]
+        m = min(pos.shape[2], self.n_elem)
+        y[:, :, 1:1 + m] = pos[:, :, :m]
+        return x, y
+
     def set_state(self, x_red, time: float = 0.0) -> None:
         self.state = self.pack_state(x_red)
         self.time = float(time)

@@ -1350,3 +1350,23 @@ def test_implicit_stepper_integrates_config1_to_the_lsoda_golden(golden):
         assert abs(tip - ref) < 2e-6                                            # (measured 1.2e-6, 1.5e-6, 5.9e-7 m)
         assert np.array_equal(got[0], got[1])
     assert abs(got[0, ens.n - 2] / tight[-1][ens.n - 2] - 1.0) < 2e-5          # t = 0.1 s: 8e-6 relative
+
+
+def test_beam_shapes_follow_the_reference_indexing():
+    """BeamEnsemble.beam_shapes: extract_beam_shapes (examples/example_utilities.py:173-205) on whole-state snapshots --
+    by default with the reference's own indexing (sol.y[n_pos + 1::3]: the velocity half, SURVEY App. B-5), restated
+    here on the unpacked snapshots."""
+    cols = nitinol_columns(6, "linear")
+    ens = ensemble(cols, 2, dict(enable_gravity=True))
+    _, snaps = ens.step(40, 2e-5, impulse_amp=np.array([0.1, 0.2]), record="all", record_every=10)
+    x, y = ens.beam_shapes(snaps, 0.25)
+    assert x.shape == y.shape == (4, 2, 7)
+    sol_y = ens.unpack_snapshots(snaps).cpu().numpy()            # [n_t, B, 2n]
+    n_pos = ens.n
+    for i in range(4):
+        for b in range(2):
+            pos = sol_y[i, b][n_pos + 1::3]
+            want = np.concatenate([[0.0], [pos[j] if j < len(pos) else 0 for j in range(6)]])
+            assert np.array_equal(y[i, b], want) and np.allclose(x[i, b], 0.25 * np.arange(7))
+    _, yw = ens.beam_shapes(snaps, 0.25, as_reference=False)
+    assert np.array_equal(yw[-1, 1, 1:], sol_y[-1, 1][1:n_pos:3]) and not np.array_equal(yw, y)
