@@ -78,6 +78,9 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 #ifndef CRB_SOA
 #define CRB_SOA 1
 #endif
+#ifndef CRB_SOA_F32   // fp32 round A as 4-byte columns instead of 16-byte records (experiment switch)
+#define CRB_SOA_F32 0
+#endif
 // components (0..3) of the lane+-4 exchange that travel by ds_bpermute instead of four chained DPP moves per half:
 // the kernel is bound by vector-ALU issue, the LDS pipe has slack -- moving PART of the widest shift there balances
 // the two (all 12 ds_bpermute: LDS-issue-bound again, measured in round 1)
@@ -275,7 +278,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
     // fp64 round A is laid out as 9 columns [qn0..2 p0..2 fl0..2][NT+1] moved by 8-byte accesses (a 16-byte LDS
     // store costs 13 cycles of the store path against 2 x 6 for two 8-byte ones); fp32 keeps 16-byte records
-    constexpr bool SOA = CRB_SOA && sizeof(T) == 8;
+    constexpr bool SOA = CRB_SOA && (sizeof(T) == 8 || CRB_SOA_F32);
     auto recA = [](T* base, int th, int k) -> T& { return SOA ? base[size_t(k) * (NT + 1) + th] : base[size_t(th) * RN + k]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const ldsA = reinterpret_cast<T*>(crb_smem);

@@ -38,8 +38,10 @@ hipError_t one_held(const KParams<T>& k, int n_beams, hipStream_t st) {
     static int resident = -1;   // (per instantiation; every device of a node is the same part)
     if (shared && std::getenv("CRB_LEAN_NO_WALK") == nullptr) {
         if (resident < 0) resident = resident_groups(kernel, 64 << LOGNW, smem);
-        if (resident > 0 && groups > resident) {
-            const int rounds = (groups + resident - 1) / resident;
+        int cap = resident;
+        if (const char* env = std::getenv("CRB_LEAN_MAX_GROUPS")) cap = std::atoi(env);   // (tests: walk with a handful of beams)
+        if (cap > 0 && groups > cap) {
+            const int rounds = (groups + cap - 1) / cap;
             grid = (groups + rounds - 1) / rounds;
         }
     }

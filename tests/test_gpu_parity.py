@@ -1370,3 +1370,43 @@ def test_beam_shapes_follow_the_reference_indexing():
             assert np.array_equal(y[i, b], want) and np.allclose(x[i, b], 0.25 * np.arange(7))
     _, yw = ens.beam_shapes(snaps, 0.25, as_reference=False)
     assert np.array_equal(yw[-1, 1, 1:], sol_y[-1, 1][1:n_pos:3]) and not np.array_equal(yw, y)
+
+
+@pytest.mark.parametrize("n_e,kind,kw,held", [
+    (64, "linear", dict(enable_gravity=True), False),                                   # one wave per beam, gravity
+    (130, "mixed", dict(fluid_density=1000.0, enable_fluid=True), False),               # four waves, padding threads
+    (256, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), True),            # the headline shape + held input
+    (10, "linear", dict(enable_gravity=True), False),                                   # packed: six beams per wave
+    (16, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), True),             # packed + held input
+])
+def test_workgroups_walking_over_beams_match_one_workgroup_per_beam(n_e, kind, kw, held, monkeypatch):
+    """The lean stepper's workgroups walk over several beams with the solve tables kept in registers (the grid is
+    capped at what is resident; CRB_LEAN_MAX_GROUPS caps it at 3 here so that 23 beams -- or 4 wave-groups of packed
+    beams -- are split unevenly over the workgroups): bitwise equal to one workgroup per beam (CRB_LEAN_NO_WALK), incl.
+    strided recording and whole-state snapshots from inside the walk."""
+    kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)] if kind == "mixed" else kind
+    cols = nitinol_columns(n_e, kinds)
+    B = 23
+    rng = np.random.default_rng(n_e)
+    x0 = rng.normal(0.0, 1e-6, (B, 6 * n_e))
+    amps = 0.05 * (1.0 + np.arange(B) / B)
+    u = rng.normal(0.0, 1e-3, (B, 3 * n_e)) if held else None
+    outs = []
+    for walk in (True, False):
+        if walk:
+            monkeypatch.setenv("CRB_LEAN_MAX_GROUPS", "3")
+            monkeypatch.delenv("CRB_LEAN_NO_WALK", raising=False)
+        else:
+            monkeypatch.delenv("CRB_LEAN_MAX_GROUPS", raising=False)
+            monkeypatch.setenv("CRB_LEAN_NO_WALK", "1")
+        ens = ensemble(cols, B, kw)
+        ens.set_state(x0)
+        _, tip = ens.step(30, 2e-5, impulse_amp=amps, held_force=u, record=(n_e, "w"), record_every=10)
+        _, snaps = ens.step(20, 2e-5, impulse_amp=amps, held_force=u, record="all", record_every=10)
+        outs.append((ens.unpack_state(), tip, snaps))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    ob = oracle_beam(cols, **kw)
+    if not held:
+        want, _ = ob.rk4_impulse_batch(x0, 2e-5, 50, amps)
+        assert_blocks(outs[0][0].cpu().numpy(), want, ensemble(cols, 1, kw).free_index, 1e-9)
