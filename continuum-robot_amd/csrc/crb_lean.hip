@@ -180,6 +180,33 @@ hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, 
 }
 #endif
 
+#if (CRB_LEAN_PART == 0 || CRB_LEAN_PART == 3) && !defined(CRB_FAST_BUILD)
+namespace {
+template <int LV, int LOGNW, bool GRAV>
+hipError_t implicit_by_em(const KParams<T>& k, const StiffParams<T>& q, int groups, int em, hipStream_t st) {
+    const dim3 grid(groups), block(64 << LOGNW);
+    const size_t smem = implicit_lean_lds_bytes<T>(64 << LOGNW, LOGNW);
+    switch (em) {
+        case EM_LINEAR: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_LINEAR>), grid, block, smem, st, k, q); break;
+        case EM_NONLINEAR: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_NONLINEAR>), grid, block, smem, st, k, q); break;
+        default: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_MIXED>), grid, block, smem, st, k, q); break;
+    }
+    return hipGetLastError();
+}
+}  // namespace
+// A is factorised without truncation: levels = ceil(log2 S), i.e. 6 / 7 / 8 for one / two / four waves per beam
+hipError_t launch_implicit_lean(const KParams<T>& k, const StiffParams<T>& q, int groups, int levels_full, int lognw, bool grav,
+                                int elem_mode, hipStream_t st) {
+    if (lognw == 0 && levels_full == 6)
+        return grav ? implicit_by_em<6, 0, true>(k, q, groups, elem_mode, st) : implicit_by_em<6, 0, false>(k, q, groups, elem_mode, st);
+    if (lognw == 1 && levels_full == 7)
+        return grav ? implicit_by_em<7, 1, true>(k, q, groups, elem_mode, st) : implicit_by_em<7, 1, false>(k, q, groups, elem_mode, st);
+    if (lognw == 2 && levels_full == 8)
+        return grav ? implicit_by_em<8, 2, true>(k, q, groups, elem_mode, st) : implicit_by_em<8, 2, false>(k, q, groups, elem_mode, st);
+    return hipErrorInvalidValue;
+}
+#endif
+
 #if CRB_LEAN_PART == 0 || CRB_LEAN_PART == 3
 hipError_t launch_stage_lean(const KParams<T>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st) {
 #ifdef CRB_FAST_BUILD  // kernel-tuning build: the config-5 instance (128 linear elements + gravity, fp64)

@@ -18,4 +18,10 @@ hipError_t launch_stage_lean(const KParams<float>& k, int n_groups, int levels, 
 // waves, levels 3..6); hipErrorInvalidValue otherwise
 hipError_t launch_rk45_lean(const KParams<double>& k, const Rk45Params& q, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st);
 hipError_t launch_rk45_lean(const KParams<float>& k, const Rk45Params& q, int n_beams, int levels, int lognw, int elem_mode, hipStream_t st);
+// launches crb_implicit_lean_kernel (crb_stiff.h) on `groups` workgroups, each walking over beams; (lognw, levels_full) in
+// {(0, 6), (1, 7), (2, 8)}: 33..64 / 65..128 / 129..256 slots per beam; hipErrorInvalidValue otherwise
+hipError_t launch_implicit_lean(const KParams<double>& k, const StiffParams<double>& q, int groups, int levels_full, int lognw,
+                                bool grav, int elem_mode, hipStream_t st);
+hipError_t launch_implicit_lean(const KParams<float>& k, const StiffParams<float>& q, int groups, int levels_full, int lognw,
+                                bool grav, int elem_mode, hipStream_t st);
 }  // namespace crb

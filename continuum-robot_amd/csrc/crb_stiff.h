@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "crb_generic.h"
+#include "crb_lean.h"
 
 namespace crb {
 
@@ -153,6 +154,210 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<
             p.x[xoff + c] = q0[c];
             p.x[xoff + plane + c] = v0[c];
         }
+    }
+}
+
+// ------------------------------------------------------------------ lean form
+// crb_implicit_lean_kernel: the same scheme through the lean stepper's exchange structure (crb_lean.h) for the plans it
+// covers -- one beam per workgroup of 1, 2 or 4 waves (64 ... 256 slots), gravity absent or of the plain cantilever's
+// nearest-neighbour form: compile-time topology, one exchange of {q_m, a_m} for the element force and the K0 a term, the
+// merged {p, f_left} + level-0 round, levels inside the wave by DPP / ds_bpermute; the workgroup walks over beams with
+// its rows of A's tables in registers (all LV = ceil(log2 S) levels: 85 values at 256 slots, one wave per SIMD).
+template <typename T>
+__host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) {
+    return sizeof(T) * size_t(NT + 1) * size_t(12 + 3 * (lognw > 1 ? lognw - 1 : 0));
+}
+template <typename T, int LV, int LOGNW, bool GRAV, int EM>
+__global__ void __launch_bounds__(64 << LOGNW, 1) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
+    static_assert(LV >= 1, "needs at least one reduction level");
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
+    T* const ldsQ = reinterpret_cast<T*>(crb_smem);            // [6][NT+1]  q_m, a_m
+    T* const ldsA = ldsQ + 6 * size_t(NT + 1);                 // [6][NT+1]  p0..2, fl0..2
+    T* const ldsB = ldsA + 6 * size_t(NT + 1);                 // [LOGNW-1][3][NT+1]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int S = p.S;
+    const int j = (lane << LOGNW) | wave;
+    const bool valid = j < S;
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+    const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S;
+    if (LOGNW > 0) {
+        if (t < 12 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)) ldsQ[size_t(t) * (NT + 1) + NULLT] = T(0);   // the "no neighbour" entries
+        __syncthreads();
+    }
+    const bool shared_tables = p.slot_stride == 0 && q.alv_stride == 0 && q.afin_stride == 0;
+    const bool corrected = (p.flags & 4u) != 0;
+    ElemCoef<T> ec;
+    T dragc = T(0), hm_own = T(0), hm_left = T(0);
+    T mask[3] = {T(0), T(0), T(0)};
+    T lin[5] = {T(0), T(0), T(0), T(0), T(0)};
+    bool shipped_nl = false;   // the element left of this node is a nonlinear one with the shipped f1 (no u2 term in its tangent)
+    SolveCoef<T, LV> cf;
+    auto load_tables = [&](int beam) {
+        if (valid) {
+            const SlotConst<T>* st = p.slot + size_t(beam) * p.slot_stride;
+            const SlotConst<T>& sc = st[j];
+            ec = sc.elem;
+            dragc = (p.flags & 1u) ? sc.drag : T(0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mask[c] = sc.mask[c];
+            if (GRAV) { hm_own = sc.half_mass; hm_left = has_left ? st[j - 1].half_mass : T(0); }
+            elem_linear_coefs<T>(ec.c, ec.kind, lin);
+            shipped_nl = ec.kind == KIND_NONLINEAR && !corrected;
+#pragma unroll
+            for (int l = 0; l < LV; ++l) {
+                const T* src = q.a_levels + size_t(beam) * q.alv_stride + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = src[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = q.a_final[size_t(beam) * q.afin_stride + size_t(j) * PCR_FINAL_VALS + k];
+        } else {
+            ec.kind = KIND_NONE;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ec.c[k] = T(0);
+#pragma unroll
+            for (int l = 0; l < LV; ++l)
+#pragma unroll
+                for (int k = 0; k < PCR_LEVEL_VALS; ++k) cf.lv[l][k] = T(0);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cf.fin[k] = T(0);
+        }
+    };
+    if (shared_tables) load_tables(0);
+    const size_t node = size_t(valid ? j + p.off : 0);
+    const size_t plane = size_t(p.n_node) * 4;
+    const T h = T(q.h), hh = T(0.5 * q.h), alpha = T(0.25 * q.h * q.h), alpha2 = T(0.5 * q.h * q.h);
+
+    for (int beam = blockIdx.x; beam < p.B; beam += gridDim.x) {
+        if (!shared_tables) load_tables(beam);
+        const size_t xoff = size_t(beam) * 2 * plane + node * 4;
+        const size_t aoff = size_t(beam) * plane + node * 4;
+        T q0[3] = {T(0), T(0), T(0)}, v0[3] = {T(0), T(0), T(0)}, am[3] = {T(0), T(0), T(0)}, uh[3] = {T(0), T(0), T(0)};
+        T amp = T(0), gx = p.gx, gy = p.gy;
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                q0[c] = p.x[xoff + c] * mask[c];
+                v0[c] = p.x[xoff + plane + c] * mask[c];
+                if (p.u_held) uh[c] = p.u_held[aoff + c];
+            }
+            if (p.amp && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
+            if (GRAV && p.gvec) { gx = p.gvec[2 * size_t(beam)]; gy = p.gvec[2 * size_t(beam) + 1]; }
+        }
+        double tc = p.t0;
+        for (int step = 0; step < p.n_steps; ++step) {
+            const double tm = __dadd_rn(tc, 0.5 * q.h), t1 = __dadd_rn(tc, q.h);
+            const T av = (tm < p.duration) ? amp : T(0);
+            T uadd[3], qp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                uadd[c] = uh[c] + ((c == p.imp_dof) ? av : T(0));
+                qp[c] = q0[c] + hh * v0[c];
+                am[c] = (step == 0) ? T(0) : am[c];
+            }
+#pragma unroll 1
+            for (int it = 0; it < q.n_iter; ++it) {
+                T qm[3], vm[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { qm[c] = qp[c] + alpha * am[c]; vm[c] = v0[c] + hh * am[c]; }
+                // -- one exchange of {q_m, a_m}: the left neighbour's values (and the right neighbour's phi for gravity)
+                T qL[3], zL[3], phiR = T(0);
+                if (LOGNW == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { qL[c] = lane_lower<T, 1>(qm[c], lane); zL[c] = lane_lower<T, 1>(am[c], lane); }
+                    if (GRAV) phiR = lane_higher<T, 1>(qm[2], lane);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { ldsQ[size_t(c) * (NT + 1) + t] = qm[c]; ldsQ[size_t(3 + c) * (NT + 1) + t] = am[c]; }
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { qL[c] = ldsQ[size_t(c) * (NT + 1) + t_l1]; zL[c] = ldsQ[size_t(3 + c) * (NT + 1) + t_l1]; }
+                    if (GRAV) phiR = ldsQ[size_t(2) * (NT + 1) + t_r1];
+                }
+                T fl[3], fr[3], kl[3], kr[3];
+                if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, qm, false, fl, fr);
+                else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, qm, fl, fr);
+                else elem_force<T>(ec, qL, qm, corrected, fl, fr);
+                elem_force_linear<T>(lin, zL, am, kl, kr);                   // K0 a_m (tangent at q = 0) ...
+                if (EM != EM_LINEAR && shipped_nl) kl[0] = lin[0] * zL[0];    // ... whose shipped-f1 row has no u2 term
+                T pp[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { fl[c] -= alpha * kl[c]; fr[c] -= alpha * kr[c]; pp[c] = uadd[c] - fr[c]; }
+                pp[1] += drag_force<T>(dragc, vm[1]);
+                if (GRAV) {
+                    T g_own[2], g_left[2];
+                    gravity_segment<T>(has_right ? T(0.5) * (qm[2] + phiR) : qm[2], gx, gy, hm_own, g_own);
+                    if (LOGNW == 0) {
+                        g_left[0] = lane_lower<T, 1>(g_own[0], lane);
+                        g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+                    } else {
+                        gravity_segment<T>(T(0.5) * (qL[2] + qm[2]), gx, gy, hm_left, g_left);
+                    }
+                    pp[0] += g_own[0] + g_left[0];
+                    pp[1] += g_own[1] + g_left[1];
+                }
+                // -- merged round {p, fl} + level 0, then the remaining levels and the final block inverse (of A)
+                T r[3], rlo[3], rhi[3], an[3];
+                if (LOGNW == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+                        r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+                        rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+                    }
+                } else {
+                    auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { col(c, t) = pp[c]; col(3 + c, t) = fl[c]; }
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        rlo[c] = col(c, t_l1) - fl[c];
+                        r[c] = pp[c] - col(3 + c, t_r1);
+                        rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+                    }
+                }
+                pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+                lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, an);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) am[c] = an[c];
+                // (LOGNW == 1: round A's columns are rewritten only after the next iteration's q exchange barrier;
+                //  LOGNW >= 2: the level-1 barrier in lean_reduce_tail orders this iteration's reads before the next writes)
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                q0[c] = q0[c] + h * v0[c] + alpha2 * am[c];
+                v0[c] = v0[c] + h * am[c];
+            }
+            tc = t1;
+            if (p.rec_out && valid && (step + 1) % p.rec_every == 0) {
+                const size_t k = size_t((step + 1) / p.rec_every - 1);
+                if (p.rec_slot == REC_ALL_SLOTS) {
+                    T* snap = p.rec_out + k * size_t(p.B) * 2 * plane + xoff;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { snap[c] = q0[c]; snap[plane + c] = v0[c]; }
+                    snap[3] = T(0);
+                    snap[plane + 3] = T(0);
+                } else if (j == p.rec_slot) {
+                    T val = q0[0];
+#pragma unroll
+                    for (int c = 1; c < 6; ++c) val = (c == p.rec_comp) ? (c < 3 ? q0[c] : v0[c - 3]) : val;
+                    p.rec_out[size_t(beam) * p.rec_n + k] = val;
+                }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                p.x[xoff + c] = q0[c];
+                p.x[xoff + plane + c] = v0[c];
+            }
+        }
+        if (LOGNW > 0) __syncthreads();   // the next beam's first q exchange must not overtake this beam's last LDS reads
     }
 }
 

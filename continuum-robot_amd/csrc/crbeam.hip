@@ -1153,6 +1153,22 @@ int launch_implicit(const crb_plan* p, const KParams<T>& k, const StiffParams<T>
 #ifdef CRB_FAST_BUILD
     return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: implicit stepper not built");
 #else
+    // the lean form: one beam per workgroup of 1 / 2 / 4 waves with ALL its reduction levels, gravity absent or canonical
+    const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
+    if (p->G == 1 && p->lognw <= 2 && p->NT == (64 << p->lognw) && p->levels_full == 6 + p->lognw && (!grav || p->canonical_gravity) &&
+        std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr) {
+        // one wave per SIMD (the tables of A fill the register file): 256 CUs x 4 / waves per beam workgroups are resident
+        int groups = p->B;
+        const bool shared = p->slot_stride == 0 && q.alv_stride == 0 && q.afin_stride == 0;
+        int resident = 256 * 4 / (1 << p->lognw);
+        if (const char* env = std::getenv("CRB_LEAN_MAX_GROUPS")) resident = std::atoi(env) > 0 ? std::atoi(env) : resident;   // (tests)
+        if (shared && groups > resident) {
+            const int rounds = (groups + resident - 1) / resident;
+            groups = (groups + rounds - 1) / rounds;
+        }
+        HIP_TRY(crb::launch_implicit_lean(k, q, groups, p->levels_full, p->lognw, grav, p->elem_mode, st));
+        return CRB_OK;
+    }
     switch (p->levels_full) {   // A is factorised without truncation
         case 0: return launch_implicit_lv<T, 0>(p, k, q, st);
         case 1: return launch_implicit_lv<T, 1>(p, k, q, st);

@@ -570,8 +570,51 @@ def g8_lsoda():
     np.savez_compressed(os.path.join(HERE, "g8_lsoda.npz"), **out)
 
 
+def g8_long():
+    """BASELINE config 1 over the example's FULL horizon: LSODA over the reference RHS to t = 1 s (10 linear elements +
+    gravity, tip impulse 0.1 N for t < 0.01 s; examples/example_utilities.py:153-159), sampled every 0.1 s, at
+    rtol 1e-8 / atol 1e-11 and at the example's default tolerances.  Merged into g8_lsoda.npz (keys lin10_grav_1s/*).
+    ~5 minutes."""
+    from scipy.integrate import solve_ivp
+
+    df = nitinol(10, "linear")
+    path = write_csv(df)
+    try:
+        beam = DynamicEulerBernoulliBeam(path, force_params=ForceParams(enable_gravity_effects=True))
+    finally:
+        os.unlink(path)
+    beam.create_system_func()
+    beam.create_input_func()
+    dyn = beam.get_dynamic_system()
+    n = beam.beam_model.M.shape[0]
+    times = np.round(np.arange(0.1, 1.0001, 0.1), 10)
+    out = {}
+    for tag, rtol, atol in (("default_tol", 1e-3, 1e-6), ("tight", 1e-8, 1e-11)):
+        t_start = time.time()
+        x, t0, ys, nfev = np.zeros(2 * n), 0.0, [], 0
+        for t1 in [0.01] + list(times):        # piecewise over the impulse switch-off
+            u = np.zeros(n)
+            if 0.5 * (t0 + t1) < 0.01:
+                u[-2] = 0.1
+            sol = solve_ivp(lambda t, y: dyn(t, y, u), (t0, t1), x, method="LSODA", rtol=rtol, atol=atol)
+            assert sol.success
+            x, t0, nfev = sol.y[:, -1], t1, nfev + sol.nfev
+            if t1 >= 0.1 - 1e-12:
+                ys.append(x.copy())
+        out[f"lin10_grav_1s/x_{tag}"] = np.array(ys)
+        out[f"lin10_grav_1s/nfev_{tag}"] = np.int64(nfev)
+        print(f"G8 long {tag}: tip w(1 s) = {x[n - 2]!r}, nfev {nfev} ({time.time() - t_start:.0f} s)", flush=True)
+    out["lin10_grav_1s/times"] = times
+    f = os.path.join(HERE, "g8_lsoda.npz")
+    old = dict(np.load(f, allow_pickle=False))
+    old.update(out)
+    np.savez_compressed(f, **old)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g8long"]
+    if "g8long" in which:
+        g8_long()
     if "g8" in which:
         g8_lsoda()
     if "g7" in which:

@@ -1410,3 +1410,60 @@ def test_workgroups_walking_over_beams_match_one_workgroup_per_beam(n_e, kind, k
     if not held:
         want, _ = ob.rk4_impulse_batch(x0, 2e-5, 50, amps)
         assert_blocks(outs[0][0].cpu().numpy(), want, ensemble(cols, 1, kw).free_index, 1e-9)
+
+
+def test_implicit_stepper_integrates_config1_for_the_examples_full_second(golden):
+    """The reference's CPU example end to end on the device: BASELINE config 1, 1 s of simulated time = 10000 implicit
+    steps in ONE launch with the tip displacement sampled every 0.1 s on the device (the example's t_eval), against
+    LSODA (rtol 1e-8) over the REFERENCE RHS (tests/golden/g8_lsoda.npz: lin10_grav_1s, tip w(1 s) = -0.41624141)."""
+    z = golden["g8_lsoda"]
+    ens = ensemble(beam_columns(z, "lin10_grav"), 2, force_kwargs(z, "lin10_grav"))
+    tight, times = z["lin10_grav_1s/x_tight"], z["lin10_grav_1s/times"]
+    t, tip = ens.step_implicit(10000, 1e-4, n_iter=2, impulse_amp=np.full(2, 0.1), record=(ens.n_elem, "w"), record_every=1000)
+    assert abs(t - 1.0) < 1e-9 and tip.shape == (2, 10)
+    tip = tip.cpu().numpy()
+    for k in range(10):
+        ref = tight[k][ens.n - 2]
+        assert abs(tip[0, k] - ref) < 1e-6 + 1e-3 * abs(ref), (times[k], tip[0, k], ref)    # LSODA's default tolerance band
+        assert abs(tip[0, k] - ref) < 1e-5 * max(abs(ref), 0.1)                            # (measured <= 7e-6 relative)
+    assert np.array_equal(tip[0], tip[1])
+    errs = block_errs(ens.unpack_state().cpu().numpy()[0], tight[-1], ens.free_index)
+    assert errs["w"] < 5e-5 and errs["phi"] < 4e-3, errs
+
+
+@pytest.mark.parametrize("n_e,kind,kw", [(64, "linear", dict(enable_gravity=True)),
+                                          (100, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True)),
+                                          (256, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True))])
+def test_implicit_lean_kernel_equals_the_general_one(n_e, kind, kw, monkeypatch):
+    """crb_implicit_lean_kernel (lean exchange structure, workgroups walking over beams: 7 beams on 3 workgroups here)
+    against crb_implicit_kernel (general kernel machinery, CRB_DISABLE_LEAN_IMPLICIT) and against the oracle, with
+    per-beam inputs and whole-state snapshots recorded from inside the walk."""
+    half = n_e // 2
+    kinds = (["linear"] * half + ["nonlinear"] * (n_e - half)) if kind == "mixed" else kind
+    cols = nitinol_columns(n_e, kinds)
+    B, h, steps = 7, 2e-4, 24
+    rng = np.random.default_rng(n_e)
+    x0 = rng.normal(0.0, 1e-6, (B, 6 * n_e))
+    amps = 0.05 * (1.0 + np.arange(B) / B)
+    u = rng.normal(0.0, 1e-3, (B, 3 * n_e))
+    outs = []
+    for lean in (True, False):
+        if lean:
+            monkeypatch.setenv("CRB_LEAN_MAX_GROUPS", "3")
+            monkeypatch.delenv("CRB_DISABLE_LEAN_IMPLICIT", raising=False)
+        else:
+            monkeypatch.setenv("CRB_DISABLE_LEAN_IMPLICIT", "1")
+        ens = ensemble(cols, B, kw)
+        ens.set_state(x0)
+        _, snaps = ens.step_implicit(steps, h, n_iter=2, impulse_amp=amps, impulse_duration=8 * h, held_force=u,
+                                     record="all", record_every=8)
+        outs.append((ens.unpack_state().cpu().numpy(), ens.unpack_snapshots(snaps).cpu().numpy()))
+    fi = ensemble(cols, 1, kw).free_index
+    assert_blocks(outs[0][0], outs[1][0], fi, 1e-8)
+    for k in range(3):
+        assert_blocks(outs[0][1][k], outs[1][1][k], fi, 1e-8, what=k)
+    assert np.array_equal(outs[0][1][-1], outs[0][0])       # the last snapshot is the terminal state
+    ob = oracle_beam(cols, **kw)
+    for b in (0, B - 1):
+        want = ob.implicit(x0[b], h, steps, n_iter=2, amp=amps[b], duration=8 * h, u_held=u[b])
+        assert_blocks(outs[0][0][b], want, fi, 1e-7, what=b)

@@ -242,3 +242,25 @@ def test_implicit_stepper_is_exact_in_one_iteration_for_a_linear_undamped_beam()
     n = ob.n
     energy = lambda x: 0.5 * x[n:] @ M @ x[n:] + 0.5 * x[:n] @ K @ x[:n]  # noqa: E731
     assert abs(energy(a) / energy(x0) - 1.0) < 1e-8
+
+
+def test_g8_config1_over_the_examples_full_second(golden):
+    """BASELINE config 1 integrated for the example's full 1 s (examples/example_utilities.py:153-159) by the implicit
+    stepper at h = 1e-4 s, against LSODA (rtol 1e-8) over the REFERENCE RHS sampled every 0.1 s: the tip displacement
+    stays inside the band the example asks of its own integrator (atol 1e-6 + rtol 1e-3 |w|) -- measured: within
+    4.5e-6 m / 7e-6 relative at every sample; w block <= 2e-5, phi block <= 1.5e-3."""
+    from tests.helpers import block_errs
+
+    z = golden["g8_lsoda"]
+    ob = oracle_beam(beam_columns(z, "lin10_grav"), **force_kwargs(z, "lin10_grav"))
+    tight, times = z["lin10_grav_1s/x_tight"], z["lin10_grav_1s/times"]
+    assert abs(tight[-1][ob.n - 2] - (-0.4162414128676396)) < 1e-15 and abs(times[-1] - 1.0) < 1e-12
+    x, t = np.zeros(2 * ob.n), 0.0
+    for k, t1 in enumerate(times):
+        x = ob.implicit(x, 1e-4, 1000, n_iter=2, amp=0.1, t0=t)     # (chunked calls: each restarts the iteration from 0)
+        t = float(t1)
+        ref = tight[k][ob.n - 2]
+        assert abs(x[ob.n - 2] - ref) < 1e-6 + 1e-3 * abs(ref)
+        assert abs(x[ob.n - 2] - ref) < 1e-5 * max(abs(ref), 0.1)
+        errs = block_errs(x, tight[k], ob.red2full())
+        assert errs["w"] < 5e-5 and errs["phi"] < 4e-3, (t1, errs)
