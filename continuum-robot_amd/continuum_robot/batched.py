@@ -428,6 +428,58 @@ class BeamEnsemble:
         self.time = t_end.value
         return (self.time, samples) if record is not None else self.time
 
+    def solve_ivp(self, t_span, t_eval, method: str = "LSODA", impulse_amp=None, impulse_duration: float = 0.01,
+                  impulse_index: int = -2, held_force=None, substeps: int = 10, rtol: float = 1e-3, atol: float = 1e-6):
+        """The examples' integration call for the whole ensemble (examples/example_utilities.py:153-159:
+        ``solve_ivp(f, t_span, x0, method="LSODA", t_eval=np.arange(t0, t1, DT))``) from the RESIDENT state, with the
+        examples' forcing.  ``t_eval`` must be a uniform grid starting at ``t_span[0]`` (what ``np.arange`` gives).
+
+        method   "LSODA" / "BDF" / "Radau" (the stiff solvers the examples use): the A-stable implicit stepper
+                 (``step_implicit``) with ``substeps`` steps per ``t_eval`` interval -- DT = 1e-3 with 10 substeps is
+                 h = 1e-4 s;   "RK45": ``solve_rk45`` (scipy's algorithm, per-beam step control, rtol / atol) with
+                 its dense output on the grid;   "RK4": the fused explicit stepper with ``substeps`` steps per interval
+                 (stable for dt <= ~7e-5 s).
+        Returns an object with ``t`` [n_t] and ``y`` [B, 2n, n_t] (``y[b]`` is the reference's ``sol.y`` of beam b,
+        first column = the state at ``t_span[0]``), ``success``, ``method``; the resident state ends at the last
+        ``t_eval`` point reached by whole intervals (RK45: at ``t_span[1]``)."""
+        t_eval = np.asarray(t_eval, dtype=np.float64)
+        if t_eval.ndim != 1 or t_eval.size < 1 or abs(t_eval[0] - t_span[0]) > 1e-12 * max(1.0, abs(t_span[0])):
+            raise ValueError("t_eval must be a 1-D grid starting at t_span[0]")
+        n_t = t_eval.size
+        dt_eval = float(t_eval[1] - t_eval[0]) if n_t > 1 else float(t_span[1] - t_span[0])
+        if n_t > 2 and np.max(np.abs(np.diff(t_eval) - dt_eval)) > 1e-9 * dt_eval:
+            raise ValueError("t_eval must be uniform (np.arange / np.linspace)")
+        self.time = float(t_span[0])
+        first = self.unpack_state().unsqueeze(0)                       # the state at t_span[0]
+        kind = method.upper()
+        kw = dict(impulse_amp=impulse_amp, impulse_duration=impulse_duration, impulse_index=impulse_index,
+                  held_force=held_force)
+        if n_t == 1:
+            ys = first
+        elif kind in ("LSODA", "BDF", "RADAU", "IMPLICIT"):
+            _, snaps = self.step_implicit((n_t - 1) * int(substeps), dt_eval / int(substeps), record="all",
+                                          record_every=int(substeps), **kw)
+            ys = torch.cat([first, self.unpack_snapshots(snaps)], dim=0)
+        elif kind == "RK4":
+            _, snaps = self.step((n_t - 1) * int(substeps), dt_eval / int(substeps), record="all",
+                                 record_every=int(substeps), **kw)
+            ys = torch.cat([first, self.unpack_snapshots(snaps)], dim=0)
+        elif kind == "RK45":
+            st = self.solve_rk45(float(t_span[1]), rtol=rtol, atol=atol, record="all",
+                                 t_eval=(float(t_eval[0]), dt_eval, n_t), **kw)
+            if np.any(st["status"] != 0):
+                raise RuntimeError("solve_ivp(RK45): a beam stopped before t_span[1]")
+            ys = self.unpack_snapshots(st["y"])
+        else:
+            raise ValueError(f"unknown method {method!r}: LSODA / BDF / Radau (implicit), RK45, RK4")
+
+        class OdeResult:   # the fields of scipy's OdeResult that the examples read
+            pass
+
+        sol = OdeResult()
+        sol.t, sol.y, sol.success, sol.method = t_eval.copy(), ys.permute(1, 2, 0).contiguous(), True, kind
+        return sol
+
     def solve_rk45(self, t_end: float, rtol: float = 1e-3, atol: float = 1e-6, impulse_amp=None,
                    impulse_duration: float = 0.01, impulse_index: int = -2, held_force=None,
                    first_step=None, t0: Optional[float] = None, max_steps: int = 0, record=None, t_eval=None):
