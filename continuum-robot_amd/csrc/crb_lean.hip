@@ -197,12 +197,14 @@ hipError_t implicit_by_em(const KParams<T>& k, const StiffParams<T>& q, int grou
 // A is factorised without truncation: levels = ceil(log2 S), i.e. 6 / 7 / 8 for one / two / four waves per beam
 hipError_t launch_implicit_lean(const KParams<T>& k, const StiffParams<T>& q, int groups, int levels_full, int lognw, bool grav,
                                 int elem_mode, hipStream_t st) {
-    if (lognw == 0 && levels_full == 6)
-        return grav ? implicit_by_em<6, 0, true>(k, q, groups, elem_mode, st) : implicit_by_em<6, 0, false>(k, q, groups, elem_mode, st);
-    if (lognw == 1 && levels_full == 7)
-        return grav ? implicit_by_em<7, 1, true>(k, q, groups, elem_mode, st) : implicit_by_em<7, 1, false>(k, q, groups, elem_mode, st);
-    if (lognw == 2 && levels_full == 8)
-        return grav ? implicit_by_em<8, 2, true>(k, q, groups, elem_mode, st) : implicit_by_em<8, 2, false>(k, q, groups, elem_mode, st);
+    if constexpr (sizeof(T) == 8) {   // (fp64 plans only: crb_step_implicit refuses fp32)
+        if (lognw == 0 && levels_full == 6)
+            return grav ? implicit_by_em<6, 0, true>(k, q, groups, elem_mode, st) : implicit_by_em<6, 0, false>(k, q, groups, elem_mode, st);
+        if (lognw == 1 && levels_full == 7)
+            return grav ? implicit_by_em<7, 1, true>(k, q, groups, elem_mode, st) : implicit_by_em<7, 1, false>(k, q, groups, elem_mode, st);
+        if (lognw == 2 && levels_full == 8)
+            return grav ? implicit_by_em<8, 2, true>(k, q, groups, elem_mode, st) : implicit_by_em<8, 2, false>(k, q, groups, elem_mode, st);
+    }
     return hipErrorInvalidValue;
 }
 #endif

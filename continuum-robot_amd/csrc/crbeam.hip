@@ -1215,6 +1215,8 @@ extern "C" int crb_step_implicit(const crb_plan* p, void* x, double t0, double h
     if (n_steps < 0) return fail(CRB_EINVAL, "crb_step_implicit: n_steps must be >= 0");
     if (!(h > 0)) return fail(CRB_EINVAL, "crb_step_implicit: h must be positive");
     if (n_iter < 1) return fail(CRB_EINVAL, "crb_step_implicit: n_iter must be >= 1");
+    if (p->dtype != CRB_F64)   // cond(M + h^2/4 K0) is 1e6 ... 1e9 at the step sizes this stepper is for
+        return fail(CRB_EUNSUPPORTED, "crb_step_implicit: the implicit stepper needs an fp64 plan (the iteration matrix is too ill-conditioned for fp32)");
     int rec_slot = -1, rec_comp = 0, rec_every = 1, rec_n = 0;
     void* rec_out = nullptr;
     if (rec && rec->node == CRB_RECORD_ALL) {
@@ -1252,11 +1254,8 @@ extern "C" int crb_step_implicit(const crb_plan* p, void* x, double t0, double h
     }
     if (n_steps == 0) return CRB_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return p->dtype == CRB_F64
-               ? step_implicit_impl<double>(p, x, t0, h, n_steps, n_iter, in, imp_slot, imp_dof, duration, amp, held, rec_out,
-                                            rec_slot, rec_comp, rec_every, rec_n, st)
-               : step_implicit_impl<float>(p, x, t0, h, n_steps, n_iter, in, imp_slot, imp_dof, duration, amp, held, rec_out,
-                                           rec_slot, rec_comp, rec_every, rec_n, st);
+    return step_implicit_impl<double>(p, x, t0, h, n_steps, n_iter, in, imp_slot, imp_dof, duration, amp, held, rec_out, rec_slot,
+                                      rec_comp, rec_every, rec_n, st);
 }
 
 static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage, int stage,

@@ -228,7 +228,8 @@ int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, 
  *          state dependence of drag, gravity and the geometric stiffness is not stiff); every step starts from the
  *          previous step's iterate, the first step of a call from 0.
  *   input  sampled at the step MIDPOINT (impulse: on while t + h/2 < duration), held force as in crb_step_rk4.
- *   rec    as crb_step_rk4_rec (may be NULL).  Beams of up to 256 thread-carried nodes.
+ *   rec    as crb_step_rk4_rec (may be NULL).  Beams of up to 256 thread-carried nodes; fp64 plans only
+ *          (cond(A) = 1e6 ... 1e9 at these step sizes).
  * Modes with |lambda| h >> 1 are not resolved (their amplitude is kept, their phase is not): displacements converge
  * at second order in h from h ~ 1e-3 s down, velocities only once h resolves the modes they contain. */
 int crb_step_implicit(const crb_plan* plan, void* x, double t0, double h, int n_steps, int n_iter,

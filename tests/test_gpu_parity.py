@@ -771,6 +771,14 @@ def test_new_entry_points_reject_bad_arguments():
         ens.step(10, 2e-5, record=(999, "w"))
     with pytest.raises(ValueError, match="n_beams entries"):
         ensemble([nitinol_columns(8, "linear")], 2)
+    with pytest.raises(nat.NativeError, match="h must be positive"):
+        ens.step_implicit(1, 0.0)
+    with pytest.raises(nat.NativeError, match="n_iter"):
+        ens.step_implicit(1, 1e-3, n_iter=0)
+    with pytest.raises(nat.NativeError, match="needs an fp64 plan"):
+        ensemble(nitinol_columns(40, "linear"), 2, dtype=torch.float32).step_implicit(1, 1e-3)
+    with pytest.raises(nat.NativeError, match="more than 256"):
+        ensemble(nitinol_columns(300, "linear"), 1).step_implicit(1, 1e-3)
 
 
 def test_native_feedback_rollout_entry_point_contract():
