@@ -247,8 +247,9 @@ __device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool co
 // HELD: a per-node input force held over the launch (zero-order-hold control, `u` of dynamic_system(t, x, u)
 // as an array): three more registers and three more additions per stage, so it is its own instantiation.
 // PACK (one-wave form only): beams with fewer than 64 slots, G = 64/S of them per wave (lane = g*S + j).  All
-// exchanges stay DPP lane shifts; what a shift drags across a beam boundary is cancelled by 0/1 masks on the
-// three terms where no zero multiplier does it already (q of the left node, f_left of the right neighbours).
+// exchanges stay DPP lane shifts; whatever a shift drags across a beam boundary is replaced by 0 with a SELECT (in
+// round A and in every reduction level, lean_reduce_tail<..., ISOLATE>): a diverged wave-mate's Inf / NaN must not
+// reach its neighbours through a 0 * NaN (the reference's beams are independent).
 template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false, bool PACK = false>
 // fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: the headline shape (<= 4 levels, no gravity, no held
 // input) fits 4 waves/SIMD (128 VGPRs; three 8-byte addresses spill, outside the step loop: config 4 runs 8.1e10
