@@ -83,13 +83,20 @@ hipError_t by_em(const KParams<T>& k, int n, int em, hipStream_t st) {
 }
 template <int LV, bool GRAV, bool STAGE>
 hipError_t by_nw(const KParams<T>& k, int n, int lognw, int em, hipStream_t st) {
-    switch (lognw) {
-        case 0: return by_em<LV, 0, GRAV, STAGE>(k, n, em, st);
-        case 1: return by_em<LV, 1, GRAV, STAGE>(k, n, em, st);
-        case 2: return by_em<LV, 2, GRAV, STAGE>(k, n, em, st);
-        case 3: return by_em<LV, 3, GRAV, STAGE>(k, n, em, st);
-        default: return hipErrorInvalidValue;
+    // Beams of more than 64 slots run the TRUNCATED reduction (their full one has >= 7 levels): the level count is where
+    // the multipliers fall below the unit roundoff -- 5 (6 for slowly decaying mass matrices) in fp64, 4 (5) in fp32 --
+    // so only those are instantiated for LOGNW >= 1 (crbeam.hip:lean_eligible sends anything else to the general kernel)
+    constexpr bool long_ok = sizeof(T) == 8 ? (LV == 5 || LV == 6) : (LV == 4 || LV == 5);
+    if (lognw == 0) return by_em<LV, 0, GRAV, STAGE>(k, n, em, st);
+    if constexpr (long_ok) {
+        switch (lognw) {
+            case 1: return by_em<LV, 1, GRAV, STAGE>(k, n, em, st);
+            case 2: return by_em<LV, 2, GRAV, STAGE>(k, n, em, st);
+            case 3: return by_em<LV, 3, GRAV, STAGE>(k, n, em, st);
+            default: return hipErrorInvalidValue;
+        }
     }
+    return hipErrorInvalidValue;
 }
 template <bool GRAV, bool STAGE>
 hipError_t by_lv(const KParams<T>& k, int n, int levels, int lognw, int em, hipStream_t st) {
@@ -123,12 +130,13 @@ hipError_t rk45_by_em(const KParams<T>& k, const Rk45Params& q, int n, int em, h
 }
 template <int LV>
 hipError_t rk45_by_nw(const KParams<T>& k, const Rk45Params& q, int n, int lognw, int em, hipStream_t st) {
-    switch (lognw) {
-        case 0: return rk45_by_em<LV, 0>(k, q, n, em, st);
-        case 1: return rk45_by_em<LV, 1>(k, q, n, em, st);
-        case 2: return rk45_by_em<LV, 2>(k, q, n, em, st);
-        default: return hipErrorInvalidValue;
+    constexpr bool long_ok = sizeof(T) == 8 ? (LV == 5 || LV == 6) : (LV == 4 || LV == 5);   // (as by_nw above)
+    if (lognw == 0) return rk45_by_em<LV, 0>(k, q, n, em, st);
+    if constexpr (long_ok) {
+        if (lognw == 1) return rk45_by_em<LV, 1>(k, q, n, em, st);
+        if (lognw == 2) return rk45_by_em<LV, 2>(k, q, n, em, st);
     }
+    return hipErrorInvalidValue;
 }
 }  // namespace
 

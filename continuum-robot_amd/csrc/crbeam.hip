@@ -818,12 +818,18 @@ int launch_beam_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     // solve multipliers stay in registers; 1024-thread groups get what their size allows
     if (p->NT <= 256) {
         hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 256, 2, LEAN>), grid, block, smem, st, k);
-    } else if (p->NT <= 512) {
-        if (int rc = allow_lds(crb_beam_kernel<T, MODE, LV, 512, 2, LEAN>, smem)) return rc;
-        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 512, 2, LEAN>), grid, block, smem, st, k);
+    } else if constexpr (LV >= 4) {
+        // (beams of more than 256 slots always run a truncated reduction -- their full one has 9 or 10 levels -- and the
+        //  truncation never lands below 4 levels: the multipliers of level 3 are ~1e-3; fewer levels are not built)
+        if (p->NT <= 512) {
+            if (int rc = allow_lds(crb_beam_kernel<T, MODE, LV, 512, 2, LEAN>, smem)) return rc;
+            hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 512, 2, LEAN>), grid, block, smem, st, k);
+        } else {
+            if (int rc = allow_lds(crb_beam_kernel<T, MODE, LV, 1024, 4, LEAN>, smem)) return rc;
+            hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 1024, 4, LEAN>), grid, block, smem, st, k);
+        }
     } else {
-        if (int rc = allow_lds(crb_beam_kernel<T, MODE, LV, 1024, 4, LEAN>, smem)) return rc;
-        hipLaunchKernelGGL((crb_beam_kernel<T, MODE, LV, 1024, 4, LEAN>), grid, block, smem, st, k);
+        return fail(CRB_EUNSUPPORTED, "a beam of more than 256 thread-carried nodes with fewer than 4 cyclic-reduction levels");
     }
     HIP_TRY(hipGetLastError());
     return CRB_OK;
@@ -864,8 +870,11 @@ inline bool lean_eligible(const crb_plan* p, const void* held) {
     (void)held;   // (a held input has its own instantiation of the lean stepper)
     // (G > 1: beams of fewer than 64 slots packed into one wave, the PACK instantiation of the one-wave stepper)
     const bool packed = p->G > 1 && p->lognw == 0 && p->NT == 64 && std::getenv("CRB_DISABLE_LEAN_PACK") == nullptr;
+    // (beams of more than 64 slots: only the level counts the truncated reduction lands on are built, crb_lean.hip:by_nw)
+    const int lv_long = p->dtype == CRB_F64 ? 5 : 4;
+    const bool levels_ok = p->lognw == 0 ? (p->levels >= 3 && p->levels <= 6) : (p->levels == lv_long || p->levels == lv_long + 1);
     return (!grav || p->canonical_gravity) && (p->G == 1 || packed) && p->NT == (64 << p->lognw) && p->lognw <= 3 &&
-           p->levels >= 3 && p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr;
+           levels_ok && std::getenv("CRB_DISABLE_LEAN") == nullptr;
 }
 template <typename T>
 int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
@@ -1139,12 +1148,8 @@ int launch_implicit_lv(const crb_plan* p, const KParams<T>& k, const StiffParams
     const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);
     const size_t smem = lds_bytes<T>(p->NT);
     // one wave per SIMD: the thread's rows of A's tables (10 per level, up to 8 levels) stay in registers
-    if (p->NT <= 256) {
-        hipLaunchKernelGGL((crb_implicit_kernel<T, LV, 256, 1>), grid, block, smem, st, k, q);
-    } else {
-        if (int rc = allow_lds(crb_implicit_kernel<T, LV, 1024, 4>, smem)) return rc;
-        hipLaunchKernelGGL((crb_implicit_kernel<T, LV, 1024, 4>), grid, block, smem, st, k, q);
-    }
+    if (p->NT > 256) return fail(CRB_EUNSUPPORTED, "crb_step_implicit: beams of more than 256 thread-carried nodes are not supported");
+    hipLaunchKernelGGL((crb_implicit_kernel<T, LV, 256, 1>), grid, block, smem, st, k, q);
     HIP_TRY(hipGetLastError());
     return CRB_OK;
 }
@@ -1380,9 +1385,11 @@ int launch_rk45_lv(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, 
     if (p->NT <= 256) {
         if (int rc = allow_lds(crb_rk45_kernel<T, LV, 256, 1>, smem)) return rc;
         hipLaunchKernelGGL((crb_rk45_kernel<T, LV, 256, 1>), grid, block, smem, st, k, q);
-    } else {
+    } else if constexpr (LV >= 4) {
         if (int rc = allow_lds(crb_rk45_kernel<T, LV, 1024, 1>, smem)) return rc;
         hipLaunchKernelGGL((crb_rk45_kernel<T, LV, 1024, 1>), grid, block, smem, st, k, q);
+    } else {
+        return fail(CRB_EUNSUPPORTED, "a beam of more than 256 thread-carried nodes with fewer than 4 cyclic-reduction levels");
     }
     HIP_TRY(hipGetLastError());
     return CRB_OK;
@@ -1393,8 +1400,10 @@ int launch_rk45(const crb_plan* p, const KParams<T>& k, const Rk45Params& q, hip
     return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: rk45 not built");
 #else
     // plans without gravity, one beam per workgroup of <= 4 waves: the lean RHS (crb_lean.hip)
-    if (!(p->flags & CRB_FORCE_GRAVITY) && p->NT == (64 << p->lognw) && p->lognw <= 2 && p->levels >= 3 &&
-        p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN") == nullptr) {
+    const int lv_long = p->dtype == CRB_F64 ? 5 : 4;
+    const bool levels_ok = p->lognw == 0 ? (p->levels >= 3 && p->levels <= 6) : (p->levels == lv_long || p->levels == lv_long + 1);
+    if (!(p->flags & CRB_FORCE_GRAVITY) && p->NT == (64 << p->lognw) && p->lognw <= 2 && levels_ok &&
+        std::getenv("CRB_DISABLE_LEAN") == nullptr) {
         HIP_TRY(crb::launch_rk45_lean(k, q, p->B, p->levels, p->lognw, p->elem_mode, st));
         return CRB_OK;
     }
