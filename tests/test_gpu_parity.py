@@ -1512,3 +1512,64 @@ def test_examples_solve_ivp_call_for_an_ensemble(golden):
         ens.solve_ivp((0.0, 1.0), np.array([0.0, 0.1, 0.3]))
     with pytest.raises(ValueError, match="unknown method"):
         ens.solve_ivp((0.0, 1.0), np.arange(0, 1, 0.1), method="Euler")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CRB_FUZZ_MIXED_N", "12"))))   # CRB_FUZZ_MIXED_N=200 for a long hunt
+def test_randomised_mixed_ensembles_against_oracle(seed):
+    """Differential test over random HETEROGENEOUS ensembles (f-3): every beam draws its own element count, element
+    kinds, boundary-condition column, material scaling and ForceParams (drag / gravity on or off, fluid density, gravity
+    vector); RK4 rollout with the impulse at each beam's own tip or a held input, the RHS, and the implicit stepper,
+    each beam against its own oracle in its own reduced ordering."""
+    from continuum_robot.batched import BeamEnsemble
+    from continuum_robot.models.force_params import ForceParams
+
+    rng = np.random.default_rng(5000 + seed)
+    B = int(rng.integers(2, 8))
+    big = rng.random() < 0.4
+    sizes = rng.integers(40, 200, B) if big else rng.integers(1, 30, B)
+    beams, fps = [], []
+    for b in range(B):
+        n = int(sizes[b])
+        kinds = [("nonlinear" if rng.random() < 0.5 else "linear") for _ in range(n)]
+        bcs = []
+        for i in range(n):
+            r = rng.random()
+            bcs.append("FIXED" if (i == 0 and r < 0.6) or r > 0.99 else ("PINNED" if r > 0.96 else "NONE"))
+        cols = nitinol_columns(n, kinds, bcs)
+        cols = _scaled(cols, rng)
+        beams.append(cols)
+        fps.append(ForceParams(fluid_density=float(rng.uniform(500, 1500)), enable_fluid_effects=bool(rng.random() < 0.5),
+                               enable_gravity_effects=bool(rng.random() < 0.5),
+                               gravity_vector=[float(rng.uniform(-3, 3)), float(rng.uniform(-12, -6)), 0.0]))
+    ens = BeamEnsemble.from_dataframes(beams, force_params=fps)
+    obs = [oracle_beam(beams[b], fluid_density=fps[b].fluid_density, enable_fluid=fps[b].enable_fluid_effects,
+                       enable_gravity=fps[b].enable_gravity_effects, gravity=fps[b].get_gravity_vector()) for b in range(B)]
+    assert [ob.n for ob in obs] == list(ens.n_per_beam)
+    x0 = [rng.normal(0.0, 1e-6, 2 * ob.n) for ob in obs]
+    ens.set_state(ens.pad_states(x0))
+    xd = ens.rhs().cpu().numpy()
+    for b in range(B):
+        assert_blocks(ens.beam_state(b, xd), obs[b].rhs(x0[b]), obs[b].red2full(), 1e-9, what=("rhs", seed, b))
+    steps = int(rng.integers(3, 30))
+    if rng.random() < 0.5:
+        amps = rng.uniform(0.01, 0.05, B)
+        ens.step(steps, 2e-5, impulse_amp=amps, impulse_index=-2, t0=0.0)
+        want = [obs[b].rk4_impulse(x0[b], 2e-5, steps, amps[b]) for b in range(B)]
+    else:
+        u = [rng.normal(0.0, 1e-3, ob.n) for ob in obs]
+        upad = np.zeros((B, ens.n))
+        for b in range(B):
+            upad[b, :obs[b].n] = u[b]
+        ens.step(steps, 2e-5, held_force=upad, t0=0.0)
+        want = [obs[b].rk4_held(x0[b], 2e-5, steps, u[b]) for b in range(B)]
+    for b in range(B):
+        assert np.isfinite(want[b]).all()
+        assert_blocks(ens.beam_state(b), want[b], obs[b].red2full(), 1e-8, what=("rk4", seed, b, int(sizes[b])))
+    # implicit stepper on the same ensemble
+    ens.set_state(ens.pad_states(x0))
+    amps = rng.uniform(0.01, 0.05, B)
+    ens.step_implicit(10, 1e-4, n_iter=3, impulse_amp=amps, impulse_index=-2, impulse_duration=5e-4, t0=0.0)
+    for b in range(B):
+        w = obs[b].implicit(x0[b], 1e-4, 10, n_iter=3, amp=amps[b], duration=5e-4)
+        assert np.isfinite(w).all()
+        assert_blocks(ens.beam_state(b), w, obs[b].red2full(), 1e-6, what=("implicit", seed, b, int(sizes[b])))
