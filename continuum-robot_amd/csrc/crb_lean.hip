@@ -108,16 +108,20 @@ hipError_t by_lv(const KParams<T>& k, int n, int levels, int lognw, int em, hipS
         default: return hipErrorInvalidValue;
     }
 }
+#ifndef CRB_RK45_MINW
+#define CRB_RK45_MINW 2
+#endif
 template <int LV, int LNW, int EM>
 hipError_t one_rk45(const KParams<T>& k, const Rk45Params& q, int n_beams, hipStream_t st) {
     constexpr int NT = 64 << LNW;
-    const size_t smem = rk45_lds_bytes<T>(NT);
+    constexpr int MINW = CRB_RK45_MINW;   // waves per SIMD the register allocation aims at
+    const size_t smem = rk45_lds_bytes<T>(NT, true);
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_rk45_kernel<T, LV, 256, 1, LNW, EM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_rk45_kernel<T, LV, 256, MINW, LNW, EM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((crb_rk45_kernel<T, LV, 256, 1, LNW, EM>), dim3(n_beams), dim3(NT), smem, st, k, q);
+    hipLaunchKernelGGL((crb_rk45_kernel<T, LV, 256, MINW, LNW, EM>), dim3(n_beams), dim3(NT), smem, st, k, q);
     return hipGetLastError();
 }
 template <int LV, int LNW>

@@ -15,7 +15,11 @@ namespace crb {
 // REDUCED state with scale = atol + max(|y|,|y_new|) rtol, SAFETY 0.9, factors in [0.2, 10], no growth
 // right after a rejection, FSAL, the same initial-step heuristic and end-point clipping.
 // One workgroup per beam (or several small beams per wave): every beam has its own clock and step.
-// The seven stage derivatives live in LDS ([7][6][NT], thread-private columns: no barrier).
+// The stage derivatives live in LDS (thread-private columns: no barrier).  General RHS: all of [7][6][NT].
+// Lean RHS (SLIM): 27 columns instead of 42 -- the accelerations of K0..K5 and the velocity halves of K3..K5; the
+// velocity half of K0 IS the state's velocity, those of K1 / K2 are one / two multiply-adds of K0 / K1's
+// accelerations (re-evaluated with the very expression that produced them), K6 stays in registers until the step is
+// decided.  With the lean RHS's 12 exchange columns that is 80 KB for a 256-node beam: two workgroups per CU.
 struct Rk45Params {
     double t0, t_end, rtol, atol;
     double* h_io;      // [B] in: first step (<= 0: choose like scipy), out: next step suggestion
@@ -30,6 +34,19 @@ struct Rk45Params {
     double eval_t0, eval_dt;
     int n_eval, eval_slot, eval_comp;
 };
+
+// scipy RK45.A with RK45.B as row 6 (the state of stage 6 is y_new); RK45.C with C[6] = 1
+__device__ const double RK45_W[7][6] = {{0, 0, 0, 0, 0, 0},
+                                        {1.0 / 5, 0, 0, 0, 0, 0},
+                                        {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+                                        {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+                                        {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+                                        {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+                                        {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+__device__ const double RK45_C[7] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+
+// LDS values the lean RHS exchanges through: [3 + 6 + 3][NT + 1] (lean_rhs), rounded up to an even count
+__host__ __device__ constexpr int rk45_exchange_vals(int NT) { return (12 * (NT + 1) + 1) & ~1; }
 
 template <typename T>
 __device__ __forceinline__ double block_sum(double v, double* red, int NT, int t, int base, int nthr_beam, bool per_wave_beams) {
@@ -58,9 +75,10 @@ __device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool co
 template <typename T, int LV, int MAXT, int MINW, int LNW = -1, int EM = 0>
 __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p, const Rk45Params q) {
     const int NT = blockDim.x;
+    constexpr bool SLIM = LNW >= 0;
     const Lds<T> lds = carve_lds<T>(NT);
-    T* const Ks = lds.r1 + 3 * NT;                         // [7][6][NT]
-    double* const red = reinterpret_cast<double*>(Ks + 42 * NT);  // [NT/64]
+    T* const Ks = SLIM ? lds.q + rk45_exchange_vals(NT) : lds.r1 + 3 * NT;   // SLIM: [27][NT], else [7][6][NT]
+    double* const red = reinterpret_cast<double*>(Ks + (SLIM ? 27 : 42) * NT);  // [NT/64]
     Topo tp;
     tp.t = threadIdx.x;
     tp.lane = tp.t & 63;
@@ -143,9 +161,22 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
 #pragma unroll
         for (int c = 0; c < 3; ++c) { d[c] = st[3 + c]; d[3 + c] = a[c]; }
     };
+    // K_k[c]: c < 3 the velocity half, c >= 3 the acceleration half.  SLIM keeps in LDS: columns 3k + (c-3) for the
+    // accelerations of k < 6, columns 18 + 3(k-3) + c for the velocity halves of k = 3..5
     auto putK = [&](int k, const T d[6]) {
+        if (SLIM) {
+            if (k < 6) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) Ks[(k * 6 + c) * NT + t] = d[c];
+                for (int c = 0; c < 3; ++c) Ks[(k * 3 + c) * NT + t] = d[3 + c];
+            }
+            if (k >= 3 && k < 6) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Ks[(18 + (k - 3) * 3 + c) * NT + t] = d[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) Ks[(k * 6 + c) * NT + t] = d[c];
+        }
     };
     auto rms = [&](const double v[6]) {  // scipy: norm(x) / sqrt(x.size) over the reduced state
         double s = 0.0;
@@ -154,15 +185,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
         return sqrt(block_sum<T>(s, red, NT, t, 0, 0, false) / double(q.n_state_b ? q.n_state_b[beam] : q.n_state));
     };
 
-    // Dormand-Prince tableau (scipy RK45.A / .B / .C / .E)
-    const double C5[6] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0};
-    const double A5[6][5] = {{0, 0, 0, 0, 0},
-                             {1.0 / 5, 0, 0, 0, 0},
-                             {3.0 / 40, 9.0 / 40, 0, 0, 0},
-                             {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
-                             {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
-                             {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
-    const double B5[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+    // Dormand-Prince tableau: RK45_W / RK45_C above (scipy RK45.A, .B, .C), error weights RK45.E
     const double E5[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
 
     // scipy RK45.P (dense output): y(t_old + x h) = y_old + h * sum_m x^(m+1) * sum_j K_j P[j][m]
@@ -173,6 +196,18 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
                              {0.0, 2.5548038301849423, -6.399112377351017, 3.5219323679207912},
                              {0.0, -1.3744241142186024, 3.272657752246729, -1.7672812570757455},
                              {0.0, 1.3824689317781436, -3.764937863556287, 2.382468931778144}};
+    // K_k[c] as a double, for k and c known at compile time after unrolling; `last` = K6 (registers), `hh` = the step
+    // the stage states were formed with (the velocity halves of K1 / K2 are those stage states' velocities)
+    auto getK = [&](int k, int c, const T* last, double hh) -> double {
+        if (!SLIM) return double(Ks[(k * 6 + c) * NT + t]);
+        if (k == 6) return double(last[c]);
+        if (c >= 3) return double(Ks[(k * 3 + (c - 3)) * NT + t]);
+        if (k == 0) return double(y[3 + c]);
+        if (k >= 3) return double(Ks[(18 + (k - 3) * 3 + c) * NT + t]);
+        double dy = 0.0;      // k = 1, 2: exactly the stage state's velocity (the expression of the stage loop below)
+        for (int jj = 0; jj < k; ++jj) dy += double(Ks[(jj * 3 + c) * NT + t]) * RK45_W[k][jj];
+        return double(T(double(y[3 + c]) + dy * hh));
+    };
     int ie = 0;  // next t_eval index (uniform over the workgroup)
     const bool recorder = q.eval_out && valid && tp.j == q.eval_slot;
 
@@ -217,36 +252,34 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
             if (t_new - q.t_end > 0.0) t_new = q.t_end;
             const double h = t_new - tc;
             h_abs = fabs(h);
-            // stages 1..5
-#pragma unroll
-            for (int s = 1; s < 6; ++s) {
-                T ys[6], ks[6];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    double dy = 0.0;
-                    for (int jj = 0; jj < s; ++jj) dy += double(Ks[(jj * 6 + c) * NT + t]) * A5[s][jj];
-                    ys[c] = T(double(y[c]) + dy * h);
-                }
-                deriv(tc + C5[s] * h, ys, ks);
-                putK(s, ks);
-            }
+            // stages 1..6 as ONE loop (not unrolled: a single copy of the RHS, and no interleaving of stages that would
+            // cost registers); stage 6 forms y_new with the B row and its derivative is K6 (FSAL).  Only the K of
+            // earlier stages enter (a wave-uniform test: what a later column still holds from a rejected attempt may
+            // be Inf / NaN and must not be touched, not even with a zero weight).
             T yn[6], fn[6];
+#pragma nounroll
+            for (int s = 1; s <= 6; ++s) {
+                double dy[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double acc = 0.0;
+                for (int jj = 0; jj < 6; ++jj) {
+                    if (jj < s) {
+                        const double wj = RK45_W[s][jj];
 #pragma unroll
-                for (int jj = 0; jj < 6; ++jj) acc += double(Ks[(jj * 6 + c) * NT + t]) * B5[jj];
-                yn[c] = T(double(y[c]) + h * acc);
+                        for (int c = 0; c < 6; ++c) dy[c] += getK(jj, c, nullptr, h) * wj;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) yn[c] = T(double(y[c]) + dy[c] * h);
+                deriv(tc + RK45_C[s] * h, yn, fn);
+                putK(s, fn);
             }
-            deriv(tc + h, yn, fn);
-            putK(6, fn);
             nfev += 6;
             double en[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 double e = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < 7; ++jj) e += double(Ks[(jj * 6 + c) * NT + t]) * E5[jj];
+                for (int jj = 0; jj < 7; ++jj) e += getK(jj, c, fn, h) * E5[jj];
                 const double scl = q.atol + fmax(fabs(double(y[c])), fabs(double(yn[c]))) * q.rtol;
                 en[c] = e * h / scl;
             }
@@ -262,9 +295,11 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
                         auto dense = [&](int c) {   // scipy RkDenseOutput for component c of this thread's node
                             const double x = (te - tc) / h;
                             double xp = x, acc = 0.0;
+#pragma unroll
                             for (int m = 0; m < 4; ++m) {
                                 double qm = 0.0;
-                                for (int jj = 0; jj < 7; ++jj) qm += double(Ks[(jj * 6 + c) * NT + t]) * P5[jj][m];
+#pragma unroll
+                                for (int jj = 0; jj < 7; ++jj) qm += getK(jj, c, fn, h) * P5[jj][m];
                                 acc += qm * xp;
                                 xp *= x;
                             }
@@ -273,12 +308,15 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
                         if (q.eval_slot == REC_ALL_SLOTS) {   // whole-state snapshot ie: [n_eval][B][2][n_node][4]
                             if (valid) {
                                 T* snap = static_cast<T*>(q.eval_out) + size_t(ie) * size_t(p.B) * 2 * plane + xoff;
+#pragma unroll
                                 for (int c = 0; c < 3; ++c) { snap[c] = dense(c); snap[plane + c] = dense(3 + c); }
                                 snap[3] = T(0);
                                 snap[plane + 3] = T(0);
                             }
-                        } else if (recorder) {
-                            static_cast<T*>(q.eval_out)[size_t(beam) * q.n_eval + ie] = dense(q.eval_comp);
+                        } else if (recorder) {   // (the component is a run-time value: select among compile-time ones)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c)
+                                if (c == q.eval_comp) static_cast<T*>(q.eval_out)[size_t(beam) * q.n_eval + ie] = dense(c);
                         }
                         ++ie;
                     }
@@ -313,8 +351,9 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_rk45_kernel(const KParams<T> p
     }
 }
 template <typename T>
-__host__ __device__ constexpr size_t rk45_lds_bytes(int NT) {
-    return lds_bytes<T>(NT) + size_t(42) * NT * sizeof(T) + size_t(NT / 64 + 1) * sizeof(double);
+__host__ __device__ constexpr size_t rk45_lds_bytes(int NT, bool slim = false) {
+    return (slim ? size_t(rk45_exchange_vals(NT)) * sizeof(T) : lds_bytes<T>(NT)) + size_t(slim ? 27 : 42) * NT * sizeof(T) +
+           size_t(NT / 64 + 1) * sizeof(double);
 }
 
 }  // namespace crb

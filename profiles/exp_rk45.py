@@ -9,6 +9,7 @@ from continuum_robot.models.force_params import ForceParams
 from tests.helpers import nitinol_columns
 
 B, ne = 4096, 256
+T_END = float(os.environ.get("T_END", "1e-2"))
 cols = nitinol_columns(ne, "nonlinear")
 fp = ForceParams(fluid_density=1000.0, enable_fluid_effects=True, enable_gravity_effects=False)
 ens = BeamEnsemble(cols, B, force_params=fp)
@@ -16,7 +17,7 @@ amps = 0.05 * (1.0 + np.arange(B) / B)
 for rtol, atol in ((1e-3, 1e-6), (1e-6, 1e-9)):
     ens.zero_state()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    st = ens.solve_rk45(2e-3, rtol=rtol, atol=atol, impulse_amp=amps, t0=0.0)
+    st = ens.solve_rk45(T_END, rtol=rtol, atol=atol, impulse_amp=amps, t0=0.0)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     nfev = np.asarray(st["nfev"], dtype=np.float64)
     acc = np.asarray(st["accepted"], dtype=np.float64)
