@@ -8,6 +8,7 @@ by rounding (cyclic-reduction solve vs explicit inverse, regrouped polynomial, F
 the fp64 assertions are far tighter and written next to each check.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1573,3 +1574,31 @@ def test_randomised_mixed_ensembles_against_oracle(seed):
         w = obs[b].implicit(x0[b], 1e-4, 10, n_iter=3, amp=amps[b], duration=5e-4)
         assert np.isfinite(w).all()
         assert_blocks(ens.beam_state(b), w, obs[b].red2full(), 1e-6, what=("implicit", seed, b, int(sizes[b])))
+
+
+def test_example_scripts_run_and_agree_with_the_oracle():
+    """examples/beam_comparison_ensemble.py (the reference's beam_comparison_* task lists as one ensemble) and
+    examples/lqr_ensemble.py (its lqr_control.py loop over many impulses): both run, the comparison's linear dry rod
+    follows the oracle's implicit trajectory, the LQR loop ends closer to rest than the open loop."""
+    import importlib.util
+
+    ex = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples")
+    sys.path.insert(0, ex)
+    try:
+        mods = {}
+        for name in ("beam_comparison_ensemble", "lqr_ensemble"):
+            spec = importlib.util.spec_from_file_location(f"crb_example_{name}", os.path.join(ex, name + ".py"))
+            mods[name] = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mods[name])
+        from _common import rod
+    finally:
+        sys.path.remove(ex)
+    y = mods["beam_comparison_ensemble"].main(["--elements", "6", "--t-final", "0.01"])
+    assert y.shape == (9, 36, 11) and np.isfinite(y).all()
+    ob = oracle_beam({c: rod(6, "linear")[c].to_numpy() for c in rod(6, "linear").columns})
+    want = ob.implicit(np.zeros(36), 1e-4, 100, n_iter=2, amp=0.1)
+    assert_blocks(y[0, :, -1], want, ob.red2full(), 1e-9, what="linear dry rod of the example")
+    rows = mods["lqr_ensemble"].main(["--elements", "4", "--beams", "8", "--t-final", "0.01"])
+    (_, open_tip, _), (_, lqr_tip, _) = rows
+    assert np.isfinite(open_tip).all() and np.isfinite(lqr_tip).all()
+    assert np.abs(lqr_tip).max() < np.abs(open_tip).max()
