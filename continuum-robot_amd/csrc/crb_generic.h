@@ -81,6 +81,10 @@ struct KParams {
     // index of a DOF or -1 -- the (un)packing of crb_pack_* fused into the kernel's own loads and stores
     const int32_t* red_map;
     int n_red;
+    // fused state feedback (MODE_STEP, FB instantiation; crb_step_rk4_feedback for beams that live in one wave):
+    // u = K (r - x) re-evaluated in every stage from an LDS copy of the gain.  red_map / n_red as above.
+    const T* fb_gain;          // [n_red][2 n_red] row-major, reduced ordering
+    const T* fb_ref;           // [B][2 n_red] or nullptr (= 0)
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
@@ -269,8 +273,20 @@ __device__ __forceinline__ Lds<T> carve_lds(int NT) {
 // MODE_STAGE: ONE RK4 stage of the stage-split stepper (the input force changes per stage, e.g. state
 // feedback u = K(r - x), lqr_control.py:95-111): k = f(t0, xs, u_held + impulse);
 // acc = (stage ? acc : 0) + w k;  stage < 3: out = x + c k;  stage 3: x += dt/6 acc.
-template <typename T, int MODE, int LV, int MAXT, int MINW, bool LEAN>
+// FB (MODE_STEP): state feedback inside the stages (lqr_control.py:95-111: c = K (0 - x) added to the input of every
+// RHS evaluation).  The gain sits in LDS, transposed ([2n][n]: the threads of a beam read consecutive addresses), the
+// stage's error vector r - x of every beam of the workgroup next to it in the reference's reduced ordering; a thread
+// forms the three entries of K e that belong to its node: 6n multiply-adds per stage.  For beams whose gain fits LDS
+// (<= ~28 elements); larger ensembles take the stage-split path (one MFMA GEMM per stage, crb_feedback.h).
+constexpr int FB_BATCH = 8;
+__host__ __device__ constexpr int fb_padded(int n2) { return (n2 + FB_BATCH - 1) / FB_BATCH * FB_BATCH; }
+template <typename T>
+__host__ __device__ constexpr size_t fb_lds_bytes(int NT, int G, int n) {
+    return lds_bytes<T>(NT) + (size_t(G) * fb_padded(2 * n) + size_t(fb_padded(2 * n)) * n) * sizeof(T);
+}
+template <typename T, int MODE, int LV, int MAXT, int MINW, bool LEAN, bool FB = false>
 __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p) {
+    static_assert(!FB || (MODE == MODE_STEP && !LEAN), "feedback lives in the general stepper");
     const int NT = blockDim.x;
     const Lds<T> lds = carve_lds<T>(NT);
     Topo tp;
@@ -364,6 +380,32 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
         if (p.amp && tp.j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
     }
 
+    // FB: reduced indices and reference of this node, the gain into LDS
+    const int fb_n = p.n_red, fb_n2 = 2 * p.n_red, fb_n2p = fb_padded(fb_n2);
+    T* const fbx = lds.r1 + 3 * NT;                       // [G][2n padded]  r - x of the stage, per beam of the workgroup
+    T* const fbK = fbx + size_t(p.G) * fb_n2p;            // [2n padded][n]  gain, transposed
+    T rq[3] = {T(0), T(0), T(0)}, rv[3] = {T(0), T(0), T(0)};
+    if (FB) {
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                red[c] = p.red_map[3 * node + c];
+                if (red[c] >= 0 && p.fb_ref) {
+                    rq[c] = p.fb_ref[size_t(beam) * fb_n2 + red[c]];
+                    rv[c] = p.fb_ref[size_t(beam) * fb_n2 + fb_n + red[c]];
+                }
+            }
+        }
+        for (int idx = tp.t; idx < fb_n * fb_n2; idx += NT) {
+            const int i = idx / fb_n2, k = idx - i * fb_n2;
+            fbK[size_t(k) * fb_n + i] = p.fb_gain[idx];
+        }
+        for (int idx = tp.t; idx < (fb_n2p - fb_n2) * fb_n; idx += NT) fbK[size_t(fb_n2) * fb_n + idx] = T(0);   // zero columns
+        for (int idx = tp.t; idx < p.G * (fb_n2p - fb_n2); idx += NT)
+            fbx[size_t(idx / (fb_n2p - fb_n2)) * fb_n2p + fb_n2 + idx % (fb_n2p - fb_n2)] = T(0);
+        __syncthreads();
+    }
+
     if (MODE == MODE_STAGE) {
         T xs[6] = {T(0), T(0), T(0), T(0), T(0), T(0)}, acc[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
         if (valid) {
@@ -447,6 +489,40 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
             T uadd[3], a[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) uadd[c] = (LEAN ? T(0) : uh[c]) + ((c == p.imp_dof) ? av : T(0));
+            if (FB) {
+                // (a beam lives in ONE wave here, whose LDS operations execute in order: the barrier only keeps the
+                //  compiler from moving the loads above the stores)
+                T* const e = fbx + size_t(valid ? g : 0) * fb_n2p;
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (red[c] >= 0) { e[red[c]] = rq[c] - xs[c]; e[fb_n + red[c]] = rv[c] - xs[3 + c]; }
+                }
+                __syncthreads();
+                if (valid) {
+                    const int i0 = red[0] >= 0 ? red[0] : 0, i1 = red[1] >= 0 ? red[1] : 0, i2 = red[2] >= 0 ? red[2] : 0;
+                    T u0 = T(0), u1 = T(0), u2 = T(0);
+                    // K e in batches of FB_BATCH columns: all LDS loads of a batch are issued before its first multiply-add
+                    // (one wave per SIMD here, nothing else hides the LDS latency; left to itself the scheduler
+                    // alternates load / wait / multiply-add: 200 cycles per column).  The column count is padded
+                    // to a multiple of the batch with zero columns.
+                    for (int k = 0; k < fb_n2p; k += FB_BATCH) {
+                        T ek[FB_BATCH], r0[FB_BATCH], r1[FB_BATCH], r2[FB_BATCH];
+#pragma unroll
+                        for (int qq = 0; qq < FB_BATCH; ++qq) {
+                            const T* row = fbK + size_t(k + qq) * fb_n;
+                            ek[qq] = e[k + qq]; r0[qq] = row[i0]; r1[qq] = row[i1]; r2[qq] = row[i2];
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4 * FB_BATCH, 0);   // the DS reads first ...
+#pragma unroll
+                        for (int qq = 0; qq < FB_BATCH; ++qq) { u0 += r0[qq] * ek[qq]; u1 += r1[qq] * ek[qq]; u2 += r2[qq] * ek[qq]; }
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3 * FB_BATCH, 0);   // ... then the arithmetic
+                    }
+                    uadd[0] += red[0] >= 0 ? u0 : T(0);
+                    uadd[1] += red[1] >= 0 ? u1 : T(0);
+                    uadd[2] += red[2] >= 0 ? u2 : T(0);
+                }
+            }
             stage_accel<T, LV, false, LEAN>(p, lds, sc, cf, tp, xs, xs + 3, uadd, a);
             const T w = (s == 0 || s == 3) ? T(1) : T(2);
             const T cs = (s == 2) ? dt : hdt;

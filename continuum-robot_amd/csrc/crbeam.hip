@@ -1069,14 +1069,20 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
 
 // ------------------------------------------------------------------ host-vector entry points (single-beam closures)
 namespace {
+// device copy of the full -> reduced index map (plans with one free-DOF set)
+int ensure_red_map(const crb_plan* p) {
+    if (p->d_red_map) return CRB_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_red_map), p->full2red.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_red_map, p->full2red.data(), p->full2red.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return CRB_OK;
+}
 int host_path_setup(const crb_plan* p, const char* who) {
     if (int rc = need_device(p, who)) return rc;
     if (p->dtype != CRB_F64) return fail(CRB_EUNSUPPORTED, std::string(who) + ": host-vector calls need an fp64 plan");
     if (p->mixed_topology) return fail(CRB_EUNSUPPORTED, std::string(who) + ": host-vector calls need one free-DOF set for the plan");
-    if (p->d_red_map) return CRB_OK;
+    if (p->h_stage) return CRB_OK;
+    if (int rc = ensure_red_map(p)) return rc;
     const size_t n = p->free_index.size();
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p->d_red_map), p->full2red.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(p->d_red_map, p->full2red.data(), p->full2red.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_stage), size_t(p->B) * 5 * n * sizeof(double), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_stage), p->h_stage, 0));
     HIP_TRY(hipStreamCreateWithFlags(&p->host_stream, hipStreamNonBlocking));
@@ -1289,11 +1295,87 @@ int feedback_step_launches(const crb_plan* p, void* x, void* acc, void* const bu
 }
 }  // namespace
 
+namespace {
+// Beams that live in one wave and whose gain fits LDS: the whole closed-loop rollout as ONE launch of the general
+// stepper's feedback instantiation (crb_generic.h, FB) instead of eight launches per step.
+bool fused_feedback_eligible(const crb_plan* p, const crb_input_desc* in) {
+    if (p->lognw != 0 || p->NT != 64 || p->mixed_topology || (in && in->f_held)) return false;
+    const char* env = std::getenv("CRB_FUSED_FEEDBACK");     // 0 = never, 1 = whenever the gain fits LDS, unset = choose
+    if (env && std::atoi(env) == 0) return false;
+    const size_t need = p->dtype == CRB_F64 ? fb_lds_bytes<double>(p->NT, p->G, p->n_free) : fb_lds_bytes<float>(p->NT, p->G, p->n_free);
+    if (need > size_t(144) * 1024) return false;
+    if (env) return true;
+    // a workgroup is ONE wave here: with a gain of more than ~50 KB few of them share a CU, and an ensemble that needs
+    // several rounds of workgroups is faster through the stage-split path (2048 x 27 elements: 125 against 67 us/step;
+    // 64 x 27: 31 against 48; up to 16 elements the fused form wins at every size: 21 against 40 - 48 us/step)
+    const size_t per_cu = (size_t(160) * 1024) / need;
+    const size_t groups = size_t((p->B + p->G - 1) / p->G);
+    return need <= size_t(52) * 1024 || groups <= per_cu * 256;
+}
+template <typename T, int LV>
+int launch_fused_feedback_lv(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
+    const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);
+    const size_t smem = fb_lds_bytes<T>(p->NT, p->G, p->n_free);
+    if (int rc = allow_lds(crb_beam_kernel<T, MODE_STEP, LV, 64, 1, false, true>, smem)) return rc;
+    hipLaunchKernelGGL((crb_beam_kernel<T, MODE_STEP, LV, 64, 1, false, true>), grid, block, smem, st, k);
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}
+template <typename T>
+int fused_feedback_impl(const crb_plan* p, void* x, double t0, double dt, int n_steps, const void* gain, const void* ref,
+                        const crb_input_desc* in, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: generic kernels not built");
+#else
+    if (int rc = ensure_red_map(p)) return rc;
+    KParams<T> k = base_params<T>(p);
+    k.x = static_cast<T*>(x);
+    k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+    k.rec_slot = -1; k.rec_every = 1;
+    if (in && in->kind == CRB_INPUT_IMPULSE) {
+        k.amp = static_cast<const T*>(in->amp);
+        k.imp_slot = in->node - p->off; k.imp_dof = in->dof; k.duration = in->duration;
+        k.imp_node_b = in->node_b;
+    }
+    k.red_map = p->d_red_map;
+    k.n_red = p->n_free;
+    k.fb_gain = static_cast<const T*>(gain);
+    k.fb_ref = static_cast<const T*>(ref);
+    switch (p->levels) {   // (a beam inside one wave: at most 6 levels)
+        case 0: return launch_fused_feedback_lv<T, 0>(p, k, st);
+        case 1: return launch_fused_feedback_lv<T, 1>(p, k, st);
+        case 2: return launch_fused_feedback_lv<T, 2>(p, k, st);
+        case 3: return launch_fused_feedback_lv<T, 3>(p, k, st);
+        case 4: return launch_fused_feedback_lv<T, 4>(p, k, st);
+        case 5: return launch_fused_feedback_lv<T, 5>(p, k, st);
+        case 6: return launch_fused_feedback_lv<T, 6>(p, k, st);
+        default: return fail(CRB_EUNSUPPORTED, "crb_step_rk4_feedback: unsupported number of cyclic-reduction levels");
+    }
+#endif
+}
+}  // namespace
+
 extern "C" int crb_step_rk4_feedback(const crb_plan* p, void* x, double t0, double dt, int n_steps, const void* gain,
                                      const void* ref, const crb_input_desc* in, void* work, double* t_end, void* stream) {
     if (int rc = need_device(p, "crb_step_rk4_feedback")) return rc;
     if (!x || !gain || !work) return fail(CRB_EINVAL, "crb_step_rk4_feedback: null pointer");
     if (n_steps < 0 || !(dt > 0)) return fail(CRB_EINVAL, "crb_step_rk4_feedback: n_steps >= 0 and dt > 0 required");
+    if (fused_feedback_eligible(p, in)) {
+        if (in && in->kind == CRB_INPUT_IMPULSE &&
+            (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp || !p->any_free[3 * in->node + in->dof]))
+            return fail(CRB_EINVAL, "crb_step_rk4_feedback: bad impulse description");
+        if (in && in->kind != CRB_INPUT_IMPULSE && in->kind != CRB_INPUT_NONE)
+            return fail(CRB_EINVAL, "crb_step_rk4_feedback: unknown input kind");
+        if (t_end) {
+            double t = t0;
+            for (int i = 0; i < n_steps; ++i) t = t + dt;
+            *t_end = t;
+        }
+        if (n_steps == 0) return CRB_OK;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        return p->dtype == CRB_F64 ? fused_feedback_impl<double>(p, x, t0, dt, n_steps, gain, ref, in, st)
+                                   : fused_feedback_impl<float>(p, x, t0, dt, n_steps, gain, ref, in, st);
+    }
     const size_t state = size_t(p->B) * 2 * p->n_node * 4 * (p->dtype == CRB_F64 ? sizeof(double) : sizeof(float));
     char* w = static_cast<char*>(work);
     void* acc = w;

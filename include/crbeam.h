@@ -261,7 +261,11 @@ int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void
  * (either dtype).  work: device scratch of crb_feedback_work_bytes(plan) bytes (three state-sized buffers and
  * one force-sized buffer and the device clock; contents need not be initialised).  Returns the accumulated clock
  * in *t_end.  CRB_USE_GRAPH=1 in the environment replays one captured step as a hipGraph on a stream of the
- * plan's own (ordered after / before the caller's stream by events). */
+ * plan's own (ordered after / before the caller's stream by events).
+ * Beams that live in one wave (fewer than 64 thread-carried nodes: the reference's own LQR example has 6 elements)
+ * and whose gain fits LDS take ONE launch for the whole rollout instead: the general stepper with the gain resident in
+ * LDS and K (r - x) formed per stage by the node threads (12 instead of 36 us per step at 6 elements, 21 instead of
+ * 40 - 48 at 16).  CRB_FUSED_FEEDBACK=0 / 1 in the environment forces the stage-split / the fused form. */
 size_t crb_feedback_work_bytes(const crb_plan* plan);
 int crb_step_rk4_feedback(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const void* gain,
                           const void* ref, const crb_input_desc* input, void* work, double* t_end, void* stream);

@@ -1602,3 +1602,51 @@ def test_example_scripts_run_and_agree_with_the_oracle():
     (_, open_tip, _), (_, lqr_tip, _) = rows
     assert np.isfinite(open_tip).all() and np.isfinite(lqr_tip).all()
     assert np.abs(lqr_tip).max() < np.abs(open_tip).max()
+
+
+@pytest.mark.parametrize("n_e,B,kind,kw,bcs", [
+    (6, 5, "linear", dict(enable_gravity=True), None),                                  # the reference's LQR example size
+    (6, 70, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), None),          # several workgroups, 10 beams a wave
+    (10, 3, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True), "pinned"),
+    (27, 4, "linear", dict(enable_gravity=True), None),                                 # gain of 102 KB: LDS above 64 KB
+    (1, 9, "linear", dict(), None),
+])
+def test_fused_feedback_stepper_matches_the_stage_split_one_and_the_oracle(n_e, B, kind, kw, bcs, monkeypatch):
+    """Closed-loop rollouts of beams that live in one wave take ONE launch (crb_beam_kernel<..., FB>: the gain in LDS,
+    u = K (r - x) formed per stage by the node threads) instead of the stage-split path's eight launches per step:
+    against RK4 over the oracle RHS with the feedback in every stage (lqr_control.py:95-111), per DOF block, with
+    per-beam references and amplitudes from random states, and against the stage-split path (CRB_FUSED_FEEDBACK=0)."""
+    monkeypatch.setenv("CRB_FUSED_FEEDBACK", "1")   # (whenever the gain fits LDS: also where the default would not choose it)
+    rng = np.random.default_rng(100 + n_e)
+    kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)] if kind == "mixed" else kind
+    bc = None
+    if bcs == "pinned":
+        bc = ["PINNED"] + ["NONE"] * (n_e - 1)
+        bc[n_e // 2] = "PINNED"
+    cols = nitinol_columns(n_e, kinds, bc) if bc else nitinol_columns(n_e, kinds)
+    ens = ensemble(cols, B, kw)
+    n = ens.n
+    gain = rng.normal(0.0, 2e-2, (n, 2 * n))
+    ref = rng.normal(0.0, 1e-4, (B, 2 * n))
+    x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
+    amps = 0.05 * (1.0 + np.arange(B))
+    steps, dt = 60, 1e-5
+    ens.set_state(x0)
+    t = ens.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    ob = oracle_beam(cols, **kw)
+    for b in range(0, B, max(1, B // 6)):
+        want = ob.rk4_feedback(x0[b], dt, steps, gain, reference=ref[b], amp=amps[b])
+        assert_blocks(got[b], want, ens.free_index, 1e-9, what=b)
+    # no reference, no impulse
+    ens.set_state(x0)
+    ens.step_feedback(steps, dt, gain)
+    got0 = ens.unpack_state().cpu().numpy()
+    assert_blocks(got0[B - 1], ob.rk4_feedback(x0[B - 1], dt, steps, gain), ens.free_index, 1e-9)
+    # the stage-split path (GEMM + stage kernel per stage) agrees to rounding
+    monkeypatch.setenv("CRB_FUSED_FEEDBACK", "0")
+    ens2 = ensemble(cols, B, kw)
+    ens2.set_state(x0)
+    t2 = ens2.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps)
+    assert t2 == t
+    assert_blocks(ens2.unpack_state().cpu().numpy(), got, ens.free_index, 1e-10)
