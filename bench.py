@@ -230,6 +230,12 @@ def worker(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the stepper has no CPU path")
+    # CRB_BENCH_REHEARSAL=1: every rank on GPU 0 and the exchange over gloo -- the N > 1 code path (shards, chunked rollout
+    # with the asynchronous all-gather, max-reduce) run on a ONE-GPU box; its number measures nothing (the ranks
+    # share the GPU, the exchange goes through the host) and the line says so
+    rehearsal = os.environ.get("CRB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     # CRB_BENCH_FORCE_DIST=1: take the RCCL path (init, barrier, all-gather, max-reduce) even with one rank
@@ -238,7 +244,10 @@ def worker(args):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import ctypes as C
 
@@ -544,7 +553,8 @@ def worker(args):
                                       (f" in {n_chunks} chunks, chunk c overlapped with the stepping of chunk c+1" if n_chunks > 1 else ""))
                                      if dist else "none",
                        "gather_chunks": n_chunks,
-                       "plan_ms": plan_ms},
+                       "plan_ms": plan_ms,
+                       **({"rehearsal": "all ranks on GPU 0, exchange over gloo: NOT a measurement"} if rehearsal else {})},
             "roofline": roofline,
             "check": check,
         }

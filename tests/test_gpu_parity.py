@@ -1650,3 +1650,28 @@ def test_fused_feedback_stepper_matches_the_stage_split_one_and_the_oracle(n_e, 
     t2 = ens2.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps)
     assert t2 == t
     assert_blocks(ens2.unpack_state().cpu().numpy(), got, ens.free_index, 1e-10)
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on this ONE GPU (CRB_BENCH_REHEARSAL=1: both ranks on GPU 0, the exchange
+    over gloo): the launcher, the shards, the chunked rollout with its asynchronous all-gather, the max-reduced clock
+    and the JSON line of rank 0.  The number it prints measures nothing; that the two shards of the gathered ensemble
+    are finite, complete and parity-checked against the oracle does."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CRB_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "config4", "--steps", "20",
+                          "--warmup", "0", "--no-cpu-baseline", "--repeats", "1", "--gather-chunks", "2"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["config"]["gather_chunks"] == 2
+    assert line["config"]["beams_per_gpu"] == [2048, 2048] and line["scaling"] == "strong"
+    assert line["check"]["finite"] and line["check"]["gathered_beams"] == 4096
+    assert "rehearsal" in line["config"]
+    errs = line["check"]["block_err_vs_oracle_last_beam"]
+    assert max(errs.values()) < 1e-4, errs          # fp32 against the fp64 oracle at 20 steps
