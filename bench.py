@@ -571,8 +571,14 @@ def worker(args):
                     if "valu_instr_per_elem_step" in tj[key] and gain is None:
                         # the limiter that actually binds: vector-ALU issue slots (one wave instruction per
                         # SIMD every 4 cycles, 1024 SIMDs, nominal 2.4 GHz), instruction count from the PMC run
+                        # (fp64 plans: every vector instruction of that kernel holds the port for 4 cycles, measured.
+                        #  fp32 arithmetic issues faster than that -- the same formula gives 1.19 for config 4 -- so
+                        #  the fp32 line carries the instruction rate instead of a fraction)
                         lane_instr = tj[key]["valu_instr_per_elem_step"] * Bc * ne * per_launch / avg_launch_s
-                        out["roofline"]["valu_issue_frac"] = lane_instr / (1024 * 64 * VALU_CLOCK_HZ / 4)
+                        if args.dtype == "f64":
+                            out["roofline"]["valu_issue_frac"] = lane_instr / (1024 * 64 * VALU_CLOCK_HZ / 4)
+                        else:
+                            out["roofline"]["valu_wave_instr_per_s_per_simd"] = lane_instr / 64 / 1024
                         out["roofline"]["valu_source"] = tj[key].get("valu_source")
             except Exception as e:  # a malformed side file must not cost the run its result line
                 print(f"[bench] profiles/traffic.json ignored: {e}", file=sys.stderr)
