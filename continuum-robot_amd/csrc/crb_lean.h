@@ -359,7 +359,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     p = CRB_PARAMS(kp);
     const int beam = PACK ? grp * p.G + pg : grp;
     const bool valid = has_slot && (!PACK || beam < p.B);
-    const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S, has_right2 = valid && j + 2 < S;
+    const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S;
     if (!shared_tables) load_tables(valid ? beam : 0);
     T phiR = T(0);
     T gx = p.gx, gy = p.gy;
@@ -456,24 +456,25 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
             // Outside the beam a neighbour reads as zeros (DPP edge / all-zero LDS record).
             T r[3], rlo[3], rhi[3];
             if (LOGNW == 0) {
+                // one wave: no barrier to save by merging, so r is formed first and ITS neighbours are shifted in
+                // (4 lane shifts per component instead of the merged round's 6, and 3 subtractions instead of 9;
+                //  r of a neighbour is the same subtraction of the same operands, evaluated in the neighbour's lane)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     // (shuffles stay outside any condition: every lane must take part.  Lanes past
                     //  the last slot are padding threads whose p and fl are 0, wave edges shift in 0.)
                     if (GRAV && c == 2) phiR = lane_higher<T, 1>(qn[2], lane);
                     qL[c] = lane_lower<T, 1>(qn[c], lane);
-                    rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
+                    const T fl_r1 = lane_higher<T, 1>(fl[c], lane);
                     if (PACK) {   // selects, not 0/1 factors: a neighbouring beam's Inf/NaN must not leak (0 * NaN = NaN)
-                        const T fl_r1 = lane_higher<T, 1>(fl[c], lane), fl_r2 = lane_higher<T, 2>(fl[c], lane);
-                        const T pp_r1 = lane_higher<T, 1>(pp[c], lane);
                         qL[c] = has_left ? qL[c] : T(0);
-                        rlo[c] = has_left ? rlo[c] : T(0);
                         r[c] = pp[c] - (has_right ? fl_r1 : T(0));
-                        rhi[c] = has_right ? pp_r1 - (has_right2 ? fl_r2 : T(0)) : T(0);
                     } else {
-                        r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
-                        rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+                        r[c] = pp[c] - fl_r1;
                     }
+                    rlo[c] = lane_lower<T, 1>(r[c], lane);
+                    rhi[c] = lane_higher<T, 1>(r[c], lane);
+                    if (PACK) { rlo[c] = has_left ? rlo[c] : T(0); rhi[c] = has_right ? rhi[c] : T(0); }
                 }
             } else {
                 T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT + 1) * RN : 0);

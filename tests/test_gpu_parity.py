@@ -1675,3 +1675,34 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert "rehearsal" in line["config"]
     errs = line["check"]["block_err_vs_oracle_last_beam"]
     assert max(errs.values()) < 1e-4, errs          # fp32 against the fp64 oracle at 20 steps
+
+
+@pytest.mark.parametrize("n_e,B", [(10, 7), (64, 3), (130, 2)])
+@pytest.mark.parametrize("span", [0.05, 0.78, 3.0, 40.0])
+def test_gravity_rotation_kernels_over_small_and_large_angles(n_e, B, span):
+    """Gravity rotates each segment's weight by cos / sin of its mean rotation (gravity_forces.py:117-124): RHS and a
+    few steps from states whose rotations span +-span rad (small, at pi/4, beyond it, many periods: the device
+    library's range reduction) against the oracle (libm), per DOF block, for the lean and the general kernels."""
+    rng = np.random.default_rng(int(span * 100) + n_e)
+    cols = nitinol_columns(n_e, "linear")
+    kw = dict(enable_gravity=True, gravity=[1.5, -9.81, 0.0])
+    ob = oracle_beam(cols, **kw)
+    n = ob.n
+    x = rng.normal(0.0, 1e-3, (B, 2 * n))
+    x[:, 2:n:3] = rng.uniform(-span, span, (B, n // 3))          # the rotations
+    x[0, 2:n:3] = np.linspace(-span, span, n // 3)               # one beam sweeping the interval end to end
+    for env in (None, "CRB_DISABLE_LEAN"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            ens = ensemble(cols, B, kw)
+            xd = ens.rhs(x).cpu().numpy()
+            ens.set_state(x)
+            ens.step(3, 1e-6)
+            got = ens.unpack_state().cpu().numpy()
+        finally:
+            if env:
+                del os.environ[env]
+        for b in range(B):
+            assert_blocks(xd[b], ob.rhs(x[b]), ens.free_index, 1e-12, what=("rhs", env, b))
+            assert_blocks(got[b], ob.rk4_impulse(x[b], 1e-6, 3, 0.0), ens.free_index, 1e-11, what=("rk4", env, b))
