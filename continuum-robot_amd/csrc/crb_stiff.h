@@ -305,9 +305,9 @@ __global__ void __launch_bounds__(64 << LOGNW, 1) crb_implicit_lean_kernel(const
                 if (LOGNW == 0) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        rlo[c] = lane_lower<T, 1>(pp[c], lane) - fl[c];
-                        r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
-                        rhi[c] = lane_higher<T, 1>(pp[c], lane) - lane_higher<T, 2>(fl[c], lane);
+                        r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);   // (one wave: r first, then ITS neighbours -- see the stepper)
+                        rlo[c] = lane_lower<T, 1>(r[c], lane);
+                        rhi[c] = lane_higher<T, 1>(r[c], lane);
                     }
                 } else {
                     auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
