@@ -1706,3 +1706,30 @@ def test_gravity_rotation_kernels_over_small_and_large_angles(n_e, B, span):
         for b in range(B):
             assert_blocks(xd[b], ob.rhs(x[b]), ens.free_index, 1e-12, what=("rhs", env, b))
             assert_blocks(got[b], ob.rk4_impulse(x[b], 1e-6, 3, 0.0), ens.free_index, 1e-11, what=("rk4", env, b))
+
+
+def test_cantilever_rings_at_the_euler_bernoulli_natural_frequencies():
+    """Physics check of the whole path (assembly, M^-1, stepper): the free vibration of the examples' 10-element Nitinol
+    cantilever after a tip impulse, integrated for 8 s with the implicit stepper, has its spectral peaks at the analytic
+    Euler-Bernoulli natural frequencies f_n = (beta_n L)^2 sqrt(EI / (rho A L^4)) / (2 pi), beta_n L = 1.8751, 4.6941
+    (the formula the reference's examples print next to their plots, examples/example_utilities.py:208-240)."""
+    n_e = 10
+    cols = nitinol_columns(n_e, "linear")
+    ens = ensemble(cols, 2, {})
+    h, steps, every = 1e-3, 8000, 5
+    _, rec = ens.step_implicit(steps, h, n_iter=3, impulse_amp=np.array([0.1, 0.2]), impulse_duration=0.01,
+                               record=(n_e, "w"), record_every=every)
+    w = rec.cpu().numpy()
+    assert w.shape == (2, steps // every) and np.isfinite(w).all()
+    assert np.allclose(w[1], 2.0 * w[0], rtol=1e-9, atol=1e-15)          # linear: the response scales with the impulse
+    L = float(np.sum(cols["length"]))
+    EI = float(cols["elastic_modulus"][0] * cols["moment_inertia"][0])
+    rhoA = float(cols["density"][0] * cols["cross_area"][0])
+    analytic = [(bl ** 2) * np.sqrt(EI / (rhoA * L ** 4)) / (2 * np.pi) for bl in (1.875104, 4.694091)]
+    sig = (w[0] - w[0].mean()) * np.hanning(w.shape[1])
+    spec = np.abs(np.fft.rfft(sig, 8 * sig.size))                       # zero-padded: 1/64 Hz bins
+    freq = np.fft.rfftfreq(8 * sig.size, every * h)
+    for f_n in analytic:
+        band = (freq > 0.6 * f_n) & (freq < 1.4 * f_n)
+        peak = freq[band][np.argmax(spec[band])]
+        assert abs(peak - f_n) < 0.02 * f_n + 0.02, (peak, f_n)
