@@ -264,3 +264,31 @@ def test_g8_config1_over_the_examples_full_second(golden):
         assert abs(x[ob.n - 2] - ref) < 1e-5 * max(abs(ref), 0.1)
         errs = block_errs(x, tight[k], ob.red2full())
         assert errs["w"] < 5e-5 and errs["phi"] < 4e-3, (t1, errs)
+
+
+def test_oracle_cantilever_rings_at_the_analytic_natural_frequencies():
+    """The CPU statement of the implicit stepper, checked against physics rather than against another code: 8 s of free
+    vibration of the 10-element Nitinol cantilever have their spectral peaks at the Euler-Bernoulli frequencies
+    (beta_n L = 1.8751, 4.6941; the formula of examples/example_utilities.py:208-240)."""
+    from tests.helpers import nitinol_columns, oracle_beam
+
+    n_e = 10
+    cols = nitinol_columns(n_e, "linear")
+    ob = oracle_beam(cols)
+    h, every, chunks = 1e-3, 5, 1600
+    x = np.zeros(2 * ob.n)
+    w = np.empty(chunks)
+    for k in range(chunks):
+        x = ob.implicit(x, h, every, n_iter=3, amp=0.1, duration=0.01, t0=k * every * h)
+        w[k] = x[ob.n - 2]
+    L = float(np.sum(cols["length"]))
+    EI = float(cols["elastic_modulus"][0] * cols["moment_inertia"][0])
+    rhoA = float(cols["density"][0] * cols["cross_area"][0])
+    sig = (w - w.mean()) * np.hanning(w.size)
+    spec = np.abs(np.fft.rfft(sig, 8 * sig.size))
+    freq = np.fft.rfftfreq(8 * sig.size, every * h)
+    for bl in (1.875104, 4.694091):
+        f_n = (bl ** 2) * np.sqrt(EI / (rhoA * L ** 4)) / (2 * np.pi)
+        band = (freq > 0.6 * f_n) & (freq < 1.4 * f_n)
+        peak = freq[band][np.argmax(spec[band])]
+        assert abs(peak - f_n) < 0.02 * f_n + 0.02, (peak, f_n)
