@@ -597,3 +597,28 @@ def test_fused_dynamic_system_equals_the_two_call_composition(beam_files):
         one(0.0, x, np.zeros(n + 1))
     beam.create_system_func(lambda x, t: np.zeros(n))
     assert beam.get_fused_dynamic_system()(0.0, x, u).shape == (2 * n,)
+
+
+@gpu
+def test_reference_pool_pattern(beam_files):
+    """The reference's examples map `simulate_single_beam` over a process pool (examples/beam_comparison_fluid.py:82-83):
+    every worker builds its own beam and returns (name, OdeResult, seconds, stats).  The same through the drop-in: two
+    worker processes (fresh interpreters: this process has the GPU initialised and must not fork), each with its own
+    plan on the GPU; the results pickle back, agree between identical tasks and the fluid case moves less."""
+    import multiprocessing as mp
+
+    from tests.pool_worker import simulate
+
+    tasks = [("lin", beam_files[0], False, 2e-3), ("lin_again", beam_files[0], False, 2e-3), ("lin_fluid", beam_files[0], True, 2e-3),
+             ("nl", beam_files[1], False, 2e-3)]
+    with mp.get_context("spawn").Pool(2) as pool:
+        results = pool.map(simulate, tasks)
+    by = {name: (sol, secs, stats) for name, sol, secs, stats in results}
+    assert set(by) == {t[0] for t in tasks}
+    for name, (sol, secs, stats) in by.items():
+        assert sol.success and sol.y.shape[1] == 5 and np.isfinite(sol.y).all() and stats["nfev"] > 0, name
+        assert stats["pid"] != os.getpid()
+    assert np.array_equal(by["lin"][0].y, by["lin_again"][0].y)
+    n = by["lin"][0].y.shape[0] // 2
+    assert abs(by["lin"][0].y[n - 2, -1]) > 0
+    assert np.linalg.norm(by["lin_fluid"][0].y[n:, -1]) < np.linalg.norm(by["lin"][0].y[n:, -1])
