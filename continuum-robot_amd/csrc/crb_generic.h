@@ -85,6 +85,10 @@ struct KParams {
     // u = K (r - x) re-evaluated in every stage from an LDS copy of the gain.  red_map / n_red as above.
     const T* fb_gain;          // [n_red][2 n_red] row-major, reduced ordering
     const T* fb_ref;           // [B][2 n_red] or nullptr (= 0)
+    // completion flag of a ONE-workgroup launch whose output lands in host-mapped memory (crb_rhs_host): written with
+    // system scope after the output stores, so that the host can spin on it instead of waiting for the stream
+    unsigned long long* done_flag;
+    unsigned long long done_seq;
 };
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
@@ -469,6 +473,11 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
                 p.out[xoff + 3] = T(0);
                 p.out[xoff + plane + 3] = T(0);
             }
+        }
+        if (p.done_flag) {   // (one workgroup: every thread's stores are fenced to the system, then one thread raises the flag)
+            __threadfence_system();
+            __syncthreads();
+            if (tp.t == 0) __hip_atomic_store(p.done_flag, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }

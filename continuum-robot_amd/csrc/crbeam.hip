@@ -78,6 +78,7 @@ struct crb_plan {
     mutable int32_t* d_red_map = nullptr;
     mutable double* h_stage = nullptr;   // pinned + mapped: [2n | n | 2n] doubles (x, u, out)
     mutable double* d_stage = nullptr;   // the device's view of h_stage
+    mutable unsigned long long host_seq = 0;   // sequence number of the last flagged host-path launch
     mutable hipStream_t host_stream = nullptr;
     int32_t* d_n_state = nullptr;     // [B] 2 * n_free_b, or null
     std::vector<double> h_levels, h_final, h_norms, h_mass, h_stiff;
@@ -1083,9 +1084,29 @@ int host_path_setup(const crb_plan* p, const char* who) {
     if (p->h_stage) return CRB_OK;
     if (int rc = ensure_red_map(p)) return rc;
     const size_t n = p->free_index.size();
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_stage), size_t(p->B) * 5 * n * sizeof(double), hipHostMallocMapped));
+    // (+ 64 bytes: the completion flag of one-workgroup launches)
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_stage), size_t(p->B) * 5 * n * sizeof(double) + 64, hipHostMallocMapped));
+    std::memset(p->h_stage + size_t(p->B) * 5 * n, 0, 64);
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->d_stage), p->h_stage, 0));
     HIP_TRY(hipStreamCreateWithFlags(&p->host_stream, hipStreamNonBlocking));
+    return CRB_OK;
+}
+}  // namespace
+
+namespace {
+// Waits for a host-path launch.  One workgroup: the kernel raises a flag in host-mapped memory after its output stores
+// and the host spins on it (a stream synchronise costs ~8 us of wake-up latency on top of a 5 us kernel); anything else,
+// or a flag that does not come within ~200 ms (a failed launch), falls back to the stream.
+int host_path_wait(const crb_plan* p, bool flagged, unsigned long long seq) {
+    if (flagged) {
+        const size_t n = p->free_index.size();
+        volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->h_stage + size_t(p->B) * 5 * n);
+        for (long spin = 0; spin < 200000000L; ++spin) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CRB_OK;
+            __builtin_ia32_pause();
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(p->host_stream));
     return CRB_OK;
 }
 }  // namespace
@@ -1103,8 +1124,13 @@ extern "C" int crb_rhs_host(const crb_plan* p, const double* x_red, const double
     k.out = p->d_stage + B * 3 * n;
     k.red_map = p->d_red_map;
     k.n_red = int(n);
+    const bool flagged = (p->B + p->G - 1) / p->G == 1 && std::getenv("CRB_HOST_SYNC") == nullptr;
+    if (flagged) {
+        k.done_flag = reinterpret_cast<unsigned long long*>(p->d_stage + B * 5 * n);
+        k.done_seq = ++p->host_seq;
+    }
     if (int rc = launch_beam<double, MODE_RHS>(p, k, p->host_stream)) return rc;
-    HIP_TRY(hipStreamSynchronize(p->host_stream));
+    if (int rc = host_path_wait(p, flagged, k.done_seq)) return rc;
     std::memcpy(xdot_red, ho, B * 2 * n * sizeof(double));
     return CRB_OK;
 }
@@ -1120,8 +1146,13 @@ extern "C" int crb_internal_force_host(const crb_plan* p, const double* q_red, d
     k.out = p->d_stage + B * 3 * n;
     k.red_map = p->d_red_map;
     k.n_red = int(n);
+    const bool flagged = (p->B + p->G - 1) / p->G == 1 && std::getenv("CRB_HOST_SYNC") == nullptr;
+    if (flagged) {
+        k.done_flag = reinterpret_cast<unsigned long long*>(p->d_stage + B * 5 * n);
+        k.done_seq = ++p->host_seq;
+    }
     if (int rc = launch_beam<double, MODE_KQ>(p, k, p->host_stream)) return rc;
-    HIP_TRY(hipStreamSynchronize(p->host_stream));
+    if (int rc = host_path_wait(p, flagged, k.done_seq)) return rc;
     std::memcpy(k_red, ho, B * n * sizeof(double));
     return CRB_OK;
 }
