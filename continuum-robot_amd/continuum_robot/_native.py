@@ -109,8 +109,8 @@ def load():
     for name in ("crb_pack_state", "crb_unpack_state", "crb_pack_vec", "crb_unpack_vec", "crb_internal_force"):
         getattr(L, name).argtypes = [vp, vp, vp, vp]
     L.crb_rhs.argtypes = [vp, vp, vp, vp, vp]
-    L.crb_rhs_host.argtypes = [vp, _dp, _dp, _dp]
-    L.crb_internal_force_host.argtypes = [vp, _dp, _dp]
+    L.crb_rhs_host.argtypes = [vp, vp, vp, vp]             # (addresses as integers: this is the per-RHS-call path)
+    L.crb_internal_force_host.argtypes = [vp, vp, vp]
     L.crb_step_rk4.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), _dp, vp]
     L.crb_step_rk4_rec.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(InputDesc), C.POINTER(RecordDesc), _dp,
                                    vp]
@@ -229,6 +229,7 @@ class Plan:
             self.per_beam = False
             check(L.crb_plan_create(C.byref(h), self.device, self.dtype, int(n_beams), C.byref(d)))
         self.h = h
+        self._rhs_host = load().crb_rhs_host   # (bound once: the per-RHS-call path of the single-beam closures)
         lay = Layout()
         check(L.crb_plan_get_layout(self.h, C.byref(lay)))
         self.layout = lay
@@ -267,14 +268,15 @@ class Plan:
         x = np.ascontiguousarray(x_red, dtype=np.float64)
         out = np.empty_like(x)
         u = None if u_red is None else np.ascontiguousarray(u_red, dtype=np.float64)
-        check(load().crb_rhs_host(self.h, x.ctypes.data_as(_dp), u.ctypes.data_as(_dp) if u is not None else None,
-                                  out.ctypes.data_as(_dp)))
+        rc = self._rhs_host(self.h, x.ctypes.data, u.ctypes.data if u is not None else None, out.ctypes.data)
+        if rc:
+            check(rc)
         return out
 
     def internal_force_host(self, q_red):
         q = np.ascontiguousarray(q_red, dtype=np.float64)
         out = np.empty_like(q)
-        check(load().crb_internal_force_host(self.h, q.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+        check(load().crb_internal_force_host(self.h, q.ctypes.data, out.ctypes.data))
         return out
 
     # ---- inspection (host)
