@@ -311,9 +311,16 @@ def worker(args):
     amps_c = [amps[c * Bc:(c + 1) * Bc].contiguous() for c in range(n_chunks)]
     gain = None
     if cfg.get("lqr"):
+        # the gain is replicated: rank 0 solves the Riccati equation (tens of CPU-seconds at 768 states), the
+        # others receive it
         t_gain = time.perf_counter()
-        gain = torch.as_tensor(lqr_gain(ens), dtype=dtype, device=ens.device)
-        print(f"[bench] LQR gain {tuple(gain.shape)} solved in {time.perf_counter() - t_gain:.1f} s", file=sys.stderr)
+        if rank == 0:
+            gain = torch.as_tensor(lqr_gain(ens), dtype=dtype, device=ens.device)
+        else:
+            gain = torch.empty((ens.n, 2 * ens.n), dtype=dtype, device=ens.device)
+        if dist:
+            dist.broadcast(gain, src=0)
+        print(f"[bench] LQR gain {tuple(gain.shape)} ready after {time.perf_counter() - t_gain:.1f} s", file=sys.stderr)
     x0n = None
     x0_c = [None] * n_chunks
     if cfg["x0"]:
