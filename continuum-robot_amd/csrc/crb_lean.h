@@ -19,8 +19,11 @@ namespace crb {
 //   * round A moves 16-byte LDS words (record = 10 fp64 / 12 fp32 values per thread, padded so
 //     that ds_read/write_b128 are bank-conflict free); lane +-1 shifts use DPP wave_shr/wave_shl
 //     (no LDS round trip), larger lane shifts ds_bpermute.
+#ifndef CRB_RECB_F32  // fp32 cross-wave levels as one 16-byte record per thread (0: three 4-byte columns)
+#define CRB_RECB_F32 1
+#endif
 template <typename T>
-struct LeanRec {                    // [qn0 qn1 qn2 - | p0 p1 p2 fl0 | fl1 fl2 (- -)]
+struct LeanRec {                    // fp32: [qn0 qn1 qn2 - | p0 p1 p2 - | fl0 fl1 fl2 -]   (fp64: columns, see the stepper)
     static constexpr int N = sizeof(T) == 8 ? 10 : 12;   // 80 B / 48 B: conflict-free 16-byte accesses
     static constexpr int V = 16 / sizeof(T);              // values per 16-byte LDS word
 };
@@ -28,8 +31,9 @@ template <typename T>
 __host__ __device__ constexpr size_t lean_lds_bytes(int NT, int lognw) {
     // round A records (+1 all-zero "no neighbour" record; double-buffered when round A is the only
     // barrier round) + SoA buffers (+1 zero column) of the cross-wave levels 1..lognw-1
+    // (fp32: the cross-wave levels move one 16-byte record [r0 r1 r2 -] per thread instead of three 4-byte columns)
     return sizeof(T) * (size_t(NT + 1) * LeanRec<T>::N * (lognw == 1 ? 2 : 1) +
-                        3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
+                        ((sizeof(T) == 4 && CRB_RECB_F32) ? 4 : 3) * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
 }
 
 // wave_shr:1 / wave_shl:1 with bound_ctrl: a lane without a source lane reads 0 and no "old" value has
@@ -134,7 +138,9 @@ __device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
 // ISOLATE (packed beams: several beams share the wave): what a lane shift drags across a beam boundary is replaced
 // by 0 with a select -- a multiplier of exactly 0 would turn a neighbouring beam's Inf/NaN into NaN here, and
 // the reference's beams are independent (a diverged beam must not take its wave-mates with it).
-template <typename T, int LV, int LOGNW, bool ISOLATE = false>
+// RECB (fp32 stepper): a cross-wave level is ONE 16-byte store and two 16-byte loads per thread instead of 3 + 6
+// 4-byte ones -- the fp32 stepper runs four waves per SIMD and is limited by LDS instruction issue, not by bytes.
+template <typename T, int LV, int LOGNW, bool ISOLATE = false, bool RECB = false>
 __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* ldsB, int t, int lane, int j, int S,
                                                  bool valid, T r[3], T a[3]) {
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
@@ -145,13 +151,23 @@ __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* 
         if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
             if (l == 1) CRB_SETPRIO(CRB_P_L1);
             const int st = 1 << l;
-            T* buf = ldsB + size_t(l - 1) * 3 * (NT + 1);
-            buf[t] = r[0]; buf[(NT + 1) + t] = r[1]; buf[2 * (NT + 1) + t] = r[2];
-            __syncthreads();
             const int tl = (valid && j - st >= 0) ? thread_of(j - st) : NULLT;
             const int th = (valid && j + st < S) ? thread_of(j + st) : NULLT;
+            if constexpr (RECB) {
+                typedef T rec4 __attribute__((ext_vector_type(4)));
+                rec4* buf = reinterpret_cast<rec4*>(ldsB) + size_t(l - 1) * (NT + 1);
+                buf[t] = rec4{r[0], r[1], r[2], T(0)};
+                __syncthreads();
+                const rec4 lo = buf[tl], hi = buf[th];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
+                for (int c = 0; c < 3; ++c) { rlo[c] = lo[c]; rhi[c] = hi[c]; }
+            } else {
+                T* buf = ldsB + size_t(l - 1) * 3 * (NT + 1);
+                buf[t] = r[0]; buf[(NT + 1) + t] = r[1]; buf[2 * (NT + 1) + t] = r[2];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
+            }
         } else {
             if (l == LOGNW) CRB_SETPRIO(CRB_P_TAIL);
 #pragma unroll
@@ -280,6 +296,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     // fp64 round A is laid out as 9 columns [qn0..2 p0..2 fl0..2][NT+1] moved by 8-byte accesses (a 16-byte LDS
     // store costs 13 cycles of the store path against 2 x 6 for two 8-byte ones); fp32 keeps 16-byte records
     constexpr bool SOA = CRB_SOA && (sizeof(T) == 8 || CRB_SOA_F32);
+    constexpr bool RECB = sizeof(T) == 4 && CRB_RECB_F32;   // cross-wave levels as 16-byte records (fp64: 32-byte records measured 4 % slower)
     auto recA = [](T* base, int th, int k) -> T& { return SOA ? base[size_t(k) * (NT + 1) + th] : base[size_t(th) * RN + k]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const ldsA = reinterpret_cast<T*>(crb_smem);
@@ -305,7 +322,8 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
 #pragma unroll
         for (int l = 1; l < LOGNW; ++l)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ldsB[(size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
+            for (int c = 0; c < (RECB ? 4 : 3); ++c)
+                ldsB[RECB ? (size_t(l - 1) * (NT + 1) + NULLT) * 4 + c : (size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
     }
 
     // ---- per-thread constants: element pack, drag factor, the thread's rows of the solve tables.  Plans whose
@@ -494,12 +512,16 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
                     for (int c = 0; c < 3; ++c) qL[c] = recA(bufA, t_l1, c);
                 } else {
                 typedef typename Vec16<T>::type vec;
+                // record: fp32 [qn0 qn1 qn2 - | p0 p1 p2 - | fl0 fl1 fl2 -] (each neighbour's read is whole 16-byte words:
+                // left {qn, p} = words 0-1, right {p, fl} = words 1-2, second right {fl} = word 2: five loads);
+                // fp64 (experiment switch CRB_SOA=0 only) [qn0 qn1 | qn2 - | p0 p1 | p2 fl0 | fl1 fl2]
+                constexpr int F0 = sizeof(T) == 4 ? 8 : 7;
                 T out[RN];
-                out[0] = qn[0]; out[1] = qn[1]; out[2] = qn[2]; out[3] = T(0);
-                out[4] = pp[0]; out[5] = pp[1]; out[6] = pp[2];
-                out[7] = fl[0]; out[8] = fl[1]; out[9] = fl[2];
 #pragma unroll
-                for (int k = 10; k < RN; ++k) out[k] = T(0);
+                for (int k = 0; k < RN; ++k) out[k] = T(0);
+                out[0] = qn[0]; out[1] = qn[1]; out[2] = qn[2];
+                out[4] = pp[0]; out[5] = pp[1]; out[6] = pp[2];
+                out[F0] = fl[0]; out[F0 + 1] = fl[1]; out[F0 + 2] = fl[2];
                 vec* rec = reinterpret_cast<vec*>(bufA + size_t(t) * RN);
 #pragma unroll
                 for (int wv = 0; wv < RN / RV; ++wv) {
@@ -511,15 +533,15 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
                 __syncthreads();
                 T L[RN], R1[RN], R2[RN];
                 rec_load<T, 0, 6>(bufA + size_t(t_l1) * RN, L);
-                rec_load<T, GRAV ? 2 : 4, 9>(bufA + size_t(t_r1) * RN, R1);
-                rec_load<T, 7, 9>(bufA + size_t(t_r2) * RN, R2);
+                rec_load<T, GRAV ? 2 : 4, F0 + 2>(bufA + size_t(t_r1) * RN, R1);
+                rec_load<T, F0, F0 + 2>(bufA + size_t(t_r2) * RN, R2);
                 if (GRAV) phiR = R1[2];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     qL[c] = L[c];
                     rlo[c] = L[4 + c] - fl[c];
-                    r[c] = pp[c] - R1[7 + c];
-                    rhi[c] = R1[4 + c] - R2[7 + c];
+                    r[c] = pp[c] - R1[F0 + c];
+                    rhi[c] = R1[4 + c] - R2[F0 + c];
                 }
                 }
             }
@@ -527,7 +549,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
 
             // -- remaining reduction levels and the final block inverse
             T a[3];
-            lean_reduce_tail<T, LV, LOGNW, PACK>(cf, ldsB, t, lane, j, S, valid, r, a);
+            lean_reduce_tail<T, LV, LOGNW, PACK, RECB>(cf, ldsB, t, lane, j, S, valid, r, a);
 
             // -- RK4 bookkeeping
 #pragma unroll
