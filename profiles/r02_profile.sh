@@ -30,8 +30,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc config2 $c --config config2 --repeats 1
 done
 pmc config3 "TCC_HIT_sum TCC_MISS_sum" --repeats 1
-bash profiles/pmc_run.sh r02 > "$OUT/pmc_run_r02.log" 2>&1
+WALK=8 bash profiles/pmc_run.sh r02 > "$OUT/pmc_run_r02.log" 2>&1
 cp gpurun_out/pmc_r02/summary.json "$OUT/sq_config3.json" 2>/dev/null
-bash profiles/pmc_run.sh r02f32 --config config4 > "$OUT/pmc_run_r02f32.log" 2>&1
+WALK=4 bash profiles/pmc_run.sh r02f32 --config config4 > "$OUT/pmc_run_r02f32.log" 2>&1
 cp gpurun_out/pmc_r02f32/summary.json "$OUT/sq_config4.json" 2>/dev/null
 python3 profiles/r02_collect.py "$OUT"
