@@ -184,6 +184,8 @@ hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, 
 #ifdef CRB_FAST_BUILD  // kernel-tuning build (make fast): only the config-3 instance
     if (sizeof(T) == 8 && levels == 5 && lognw == 2 && !grav && elem_mode == EM_NONLINEAR)
         return one<5, 2, false, EM_NONLINEAR>(k, n_beams, st);
+    if (sizeof(T) == 4 && levels == 4 && lognw == 2 && !grav && elem_mode == EM_NONLINEAR)   // (make fast32)
+        return one<4, 2, false, EM_NONLINEAR>(k, n_beams, st);
     return hipErrorInvalidValue;
 #else
     return grav ? launch_lean_grav(k, n_beams, levels, lognw, elem_mode, st)

@@ -879,8 +879,12 @@ inline bool lean_eligible(const crb_plan* p, const void* held) {
 }
 template <typename T>
 int launch_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
-#ifdef CRB_FAST_BUILD
+#ifdef CRB_FAST_BUILD   // (make fast: the fp64 config-3 instance only; make fast32: the fp32 config-4 one)
+#ifdef CRB_FAST_F32
+    if constexpr (sizeof(T) == 8) return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD (fp32): fp64 lean stepper not built");
+#else
     if constexpr (sizeof(T) == 4) return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: fp32 lean stepper not built");
+#endif
     else
 #endif
     HIP_TRY(crb::launch_lean(k, p->B, p->levels, p->lognw, (p->flags & CRB_FORCE_GRAVITY) != 0, p->elem_mode, st));
@@ -907,7 +911,11 @@ int launch_stage_lean(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
         if (cap > 0 && groups > cap) groups = cap;
     }
 #ifdef CRB_FAST_BUILD
+#ifdef CRB_FAST_F32
+    if constexpr (sizeof(T) == 8) return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD (fp32): fp64 lean stage kernel not built");
+#else
     if constexpr (sizeof(T) == 4) return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: fp32 lean stage kernel not built");
+#endif
     else
 #endif
     HIP_TRY(crb::launch_stage_lean(k, groups, p->levels, p->lognw, (p->flags & CRB_FORCE_GRAVITY) != 0, p->elem_mode, st));
