@@ -614,17 +614,41 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
 // rotation for gravity) are plain global loads of the stage state: no exchange round for them.
 //   k = f(t_stage, xs, u_stage + impulse);  acc = (stage ? acc : 0) + w k;
 //   stage < 3: out = x + c k;   stage 3: x += dt/6 acc           (same contract as MODE_STAGE)
+#ifndef CRB_STAGE_IO   // node records through LDS in memory order (0: every thread loads / stores its own slot's records)
+#define CRB_STAGE_IO 1
+#endif
+#ifndef CRB_STAGE_PREFETCH   // load the next beam's records while the current beam is computed (needs CRB_STAGE_MINW=1: 56 more
+                             // registers; measured 21.6 vs 21.4 us at 2048 x 128, 24.6 vs 26.5 at 1024 x 256: off)
+#define CRB_STAGE_PREFETCH 0
+#endif
+#ifndef CRB_STAGE_MINW      // waves per SIMD the stage kernel's fp64 register allocation aims at
+#define CRB_STAGE_MINW 2
+#endif
+constexpr int STAGE_IO_STREAMS = 7;   // xs q / v, x q / v, acc q / v, u
 template <typename T>
 __host__ __device__ constexpr size_t stage_lean_lds_bytes(int NT, int lognw) {
-    return sizeof(T) * (size_t(NT + 1) * 6 * (lognw == 1 ? 2 : 1) + 3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
+    // exchange columns (16-byte multiple) + the record staging of the transposed I/O (beams of more than one wave)
+    const size_t cols = sizeof(T) * (size_t(NT + 1) * 6 * (lognw == 1 ? 2 : 1) + 3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
+    const size_t io = (CRB_STAGE_IO && lognw > 0 && lognw <= 2) ? size_t(STAGE_IO_STREAMS) * size_t(NT + 1) * 4 * sizeof(T) : 0;   // (eight waves: no room)
+    return ((cols + 31) / 32) * 32 + io;
 }
 template <typename T, int LV, int LOGNW, bool GRAV, int EM>
-__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_stage_lean_kernel(const KParams<T> p) {
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : CRB_STAGE_MINW) crb_stage_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stage kernel needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const ldsA = reinterpret_cast<T*>(crb_smem);                         // [1 or 2][6][NT+1]: p0..2, fl0..2
     T* const ldsB = ldsA + size_t(NT + 1) * 6 * (LOGNW == 1 ? 2 : 1);       // [level-1][3][NT+1]
+    // Transposed record I/O (beams of more than one wave).  A wave's slots are every NW-th node, so a thread that loads /
+    // stores ITS OWN slot's 32-byte records makes every 16-byte half a memory request of its own (measured at equal
+    // node count: 18 us per launch with one wave per beam, 24 with two, 31 with four).  Instead thread t moves the records
+    // of node t -- consecutive lanes, consecutive records -- and the records change hands in LDS: staged at the position
+    // of the OWNER thread (so that the owner and its stride-1 neighbours read consecutive positions), which also hands
+    // the left neighbour's q and the right neighbour's rotation over without loads of their own.
+    constexpr bool IO = CRB_STAGE_IO && LOGNW > 0 && LOGNW <= 2;
+    typedef T rec4 __attribute__((ext_vector_type(4)));
+    constexpr size_t COLS_BYTES = ((sizeof(T) * (size_t(NT + 1) * 6 * (LOGNW == 1 ? 2 : 1) + 3 * size_t(NT + 1) * size_t(LOGNW > 1 ? LOGNW - 1 : 0)) + 31) / 32) * 32;
+    rec4* const io = reinterpret_cast<rec4*>(crb_smem + COLS_BYTES);        // [7][NT+1] records, position NT = zeros
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int S = p.S;
     const int j = (lane << LOGNW) | wave;
@@ -641,10 +665,15 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
 #pragma unroll
             for (int c = 0; c < 3; ++c) ldsB[(size_t(l - 1) * 3 + c) * (NT + 1) + NULLT] = T(0);
     }
+    if (IO && t < STAGE_IO_STREAMS) io[size_t(t) * (NT + 1) + NULLT] = rec4{T(0), T(0), T(0), T(0)};
     const bool shared_tables = p.slot_stride == 0 && p.lv_stride == 0 && p.fin_stride == 0;
     const bool corrected = (p.flags & 4u) != 0;
     const bool has_right = valid && j + 1 < S, has_left = valid && j >= 1;
     const size_t node = size_t(valid ? j + p.off : 0);
+    // memory side of the transposed I/O: this thread moves the records of slot t (node t + off), whose owner is thread_of(t)
+    const bool mvalid = t < S;
+    const size_t mnode = size_t(mvalid ? t + p.off : 0);
+    const int mpos = mvalid ? thread_of(t) : NULLT;
     const size_t plane = size_t(p.n_node) * 4;
     const T w = (p.stage == 0 || p.stage == 3) ? T(1) : T(2);
     const T cs = (p.stage == 2) ? T(p.dt) : T(0.5 * p.dt);
@@ -686,16 +715,58 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     };
     if (shared_tables) load_tables(0);
 
+    rec4 pre[STAGE_IO_STREAMS];   // (IO) the records of node t of the beam about to be staged
+    auto fetch_io = [&](int beam) {
+        const rec4 z = rec4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int k = 0; k < STAGE_IO_STREAMS; ++k) pre[k] = z;
+        if (mvalid && beam < p.B) {
+            auto ldrec = [](const T* ptr) { return *reinterpret_cast<const rec4*>(ptr); };
+            const size_t moff = size_t(beam) * 2 * plane + mnode * 4;
+            pre[0] = ldrec(p.xs + moff); pre[1] = ldrec(p.xs + moff + plane);
+            pre[2] = ldrec(p.x + moff); pre[3] = ldrec(p.x + moff + plane);
+            if (p.stage > 0) { pre[4] = ldrec(p.acc + moff); pre[5] = ldrec(p.acc + moff + plane); }
+            if (p.u_held) pre[6] = ldrec(p.u_held + size_t(beam) * plane + mnode * 4);
+        }
+    };
+    if (IO && CRB_STAGE_PREFETCH) fetch_io(blockIdx.x);
     int it = 0;
     for (int beam = blockIdx.x; beam < p.B; beam += gridDim.x, ++it) {
         if (!shared_tables) load_tables(beam);
+        if (IO && !CRB_STAGE_PREFETCH) fetch_io(beam);
         // ---- this stage's state, the neighbours' pieces of it, the input force
         const size_t xoff = size_t(beam) * 2 * plane + node * 4;
         T sq[3] = {T(0), T(0), T(0)}, sv[3] = {T(0), T(0), T(0)}, qL[3] = {T(0), T(0), T(0)}, uin[3] = {T(0), T(0), T(0)};
         T x0q[3] = {T(0), T(0), T(0)}, x0v[3] = {T(0), T(0), T(0)}, aq[3] = {T(0), T(0), T(0)}, av[3] = {T(0), T(0), T(0)};
         T phiR = T(0), amp = T(0);
-        typedef T rec4 __attribute__((ext_vector_type(4)));
-        if (valid) {
+        if (IO) {
+            auto at = [&](int k, int pos) -> rec4& { return io[size_t(k) * (NT + 1) + pos]; };
+            if (mvalid) {
+#pragma unroll
+                for (int k = 0; k < STAGE_IO_STREAMS; ++k) at(k, mpos) = pre[k];
+            }
+            __syncthreads();
+            if (CRB_STAGE_PREFETCH) {   // the next beam's records travel while this one is computed
+                fetch_io(beam + int(gridDim.x));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int own = valid ? t : NULLT;
+            const rec4 rq = at(0, own), rv = at(1, own), bq = at(2, own), bv = at(3, own), cq = at(4, own), cv = at(5, own), ru = at(6, own);
+            const rec4 rl = at(0, t_l1);
+            if (GRAV) phiR = at(0, t_r1)[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sq[c] = rq[c] * mask[c];
+                sv[c] = rv[c] * mask[c];
+                qL[c] = rl[c] * maskL[c];
+                x0q[c] = bq[c] * mask[c];
+                x0v[c] = bv[c] * mask[c];
+                aq[c] = cq[c];
+                av[c] = cv[c];
+                uin[c] = ru[c];
+            }
+            if (valid && p.amp && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
+        } else if (valid) {
             // a node record is 4 values = one aligned 32-byte (fp64) / 16-byte (fp32) vector: whole-record
             // loads instead of three scalar ones (the slots of a wave are every NW-th node, so scalar loads
             // would pull each 128-byte line through L1 once per component: measured 31.7 -> 24 us)
@@ -771,7 +842,34 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         T a[3];
         lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
         // ---- RK4 bookkeeping of this stage
-        if (valid) {
+        if (IO) {
+            auto at = [&](int k, int pos) -> rec4& { return io[size_t(k) * (NT + 1) + pos]; };
+            T nq[3], nv[3], oq[3], ov[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                nq[c] = (p.stage ? aq[c] : T(0)) + w * sv[c];
+                nv[c] = (p.stage ? av[c] : T(0)) + w * a[c];
+                oq[c] = (p.stage < 3) ? x0q[c] + cs * sv[c] : x0q[c] + dt6 * nq[c];
+                ov[c] = (p.stage < 3) ? x0v[c] + cs * a[c] : x0v[c] + dt6 * nv[c];
+            }
+            // (the staging is free again: every thread read its inputs before the barrier of round A)
+            if (valid) {
+                at(0, t) = rec4{oq[0], oq[1], oq[2], T(0)}; at(1, t) = rec4{ov[0], ov[1], ov[2], T(0)};
+                if (p.stage < 3) { at(2, t) = rec4{nq[0], nq[1], nq[2], T(0)}; at(3, t) = rec4{nv[0], nv[1], nv[2], T(0)}; }
+            }
+            __syncthreads();
+            if (mvalid) {
+                const size_t moff = size_t(beam) * 2 * plane + mnode * 4;
+                auto strec = [](T* ptr, const rec4 v) { *reinterpret_cast<rec4*>(ptr) = v; };
+                if (p.stage < 3) {   // (whole records: the pad value is written as 0)
+                    strec(p.out + moff, at(0, mpos)); strec(p.out + moff + plane, at(1, mpos));
+                    strec(p.acc + moff, at(2, mpos)); strec(p.acc + moff + plane, at(3, mpos));
+                } else {
+                    strec(p.x + moff, at(0, mpos)); strec(p.x + moff + plane, at(1, mpos));
+                }
+            }
+            __syncthreads();   // the next beam's records may be staged only after these reads
+        } else if (valid) {
             auto strec = [](T* ptr, const T v[3]) { *reinterpret_cast<rec4*>(ptr) = rec4{v[0], v[1], v[2], T(0)}; };
             T nq[3], nv[3], oq[3], ov[3];
 #pragma unroll

@@ -62,6 +62,11 @@ template <int LV, int LOGNW, bool GRAV, int EM>
 hipError_t one_stage(const KParams<T>& k, int n_groups, hipStream_t st) {
     const dim3 grid(n_groups), block(64 << LOGNW);
     const size_t smem = stage_lean_lds_bytes<T>(64 << LOGNW, LOGNW);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_stage_lean_kernel<T, LV, LOGNW, GRAV, EM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((crb_stage_lean_kernel<T, LV, LOGNW, GRAV, EM>), grid, block, smem, st, k);
     return hipGetLastError();
 }
