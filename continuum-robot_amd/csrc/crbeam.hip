@@ -74,6 +74,7 @@ struct crb_plan {
     mutable void* d_alevels = nullptr;   // [nd][levels_full][S][10]
     mutable void* d_afinal = nullptr;    // [nd][S][6]
     mutable double stiff_alpha = 0.0;    // alpha the tables above were built for (0 = none yet)
+    mutable int stiff_levels = 0;        // reduction levels of A that the implicit kernels run (the rest are below roundoff)
     // host-vector entry points (crb_rhs_host): full -> reduced map on the device, pinned staging, a stream of the plan's own
     mutable int32_t* d_red_map = nullptr;
     mutable double* h_stage = nullptr;   // pinned + mapped: [2n | n | 2n] doubles (x, u, out)
@@ -1182,8 +1183,28 @@ int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
     a.alpha = alpha;
     a.slot_out = nullptr; a.lv64 = nullptr; a.fin64_all = nullptr; a.blocks0 = nullptr;
     a.lvT = p->d_alevels; a.finT = p->d_afinal; a.fin_level = lf; a.norms = in.dNormScratch.p;
+    HIP_TRY(hipMemsetAsync(in.dNormScratch.p, 0, size_t(lf > 0 ? lf : 1) * sizeof(double), st));
     hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(in.threads), in.smem, st, a);
     HIP_TRY(hipGetLastError());
+    // The reduction of A stops where its multipliers fall below the unit roundoff, like the mass matrix's (pick_levels):
+    // for the step sizes the examples use (h = 1e-4: the stride-32 multipliers of a 256-node Nitinol rod are ~1e-19) that is
+    // 5 levels instead of 8; large steps (h = 1e-3) keep them all.  One stream synchronisation per new step size.
+    int used = lf;
+    if (lf > 0 && std::getenv("CRB_STIFF_ALL_LEVELS") == nullptr) {
+        std::vector<double> norms(static_cast<size_t>(lf));
+        HIP_TRY(hipMemcpyAsync(norms.data(), in.dNormScratch.p, size_t(lf) * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        while (used > 0 && norms[size_t(used) - 1] < std::ldexp(1.0, -53)) --used;
+        // (the lean kernels exist for the full count and for 5 levels; anything between runs the full count)
+        const bool lean_shape = p->G == 1 && p->lognw <= 2 && p->NT == (64 << p->lognw) && lf == 6 + p->lognw;
+        if (lean_shape && used != 5 && std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr) used = lf;
+        if (used < lf) {   // the final block inverses after `used` levels
+            a.fin_level = used;
+            hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(in.threads), in.smem, st, a);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    p->stiff_levels = used;
     p->stiff_alpha = alpha;
     return CRB_OK;
 }
@@ -1216,10 +1237,10 @@ int launch_implicit(const crb_plan* p, const KParams<T>& k, const StiffParams<T>
             const int rounds = (groups + resident - 1) / resident;
             groups = (groups + rounds - 1) / rounds;
         }
-        HIP_TRY(crb::launch_implicit_lean(k, q, groups, p->levels_full, p->lognw, grav, p->elem_mode, st));
+        HIP_TRY(crb::launch_implicit_lean(k, q, groups, p->stiff_levels, p->lognw, grav, p->elem_mode, st));
         return CRB_OK;
     }
-    switch (p->levels_full) {   // A is factorised without truncation
+    switch (p->stiff_levels) {   // (the levels of A whose multipliers matter, stiff_tables)
         case 0: return launch_implicit_lv<T, 0>(p, k, q, st);
         case 1: return launch_implicit_lv<T, 1>(p, k, q, st);
         case 2: return launch_implicit_lv<T, 2>(p, k, q, st);

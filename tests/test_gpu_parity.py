@@ -1302,6 +1302,9 @@ def test_batched_functional_composition_matches_oracle(n_e, kind):
     (64, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), 2e-4),            # one wave per beam, 6 levels
     (130, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True), 5e-4),   # 4 waves, padding threads
     (256, "linear", dict(enable_gravity=True), 1e-3),                                  # 8 levels: the largest supported
+    (256, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), 1e-4),           # small step: A's reduction stops at 5 of 8 levels
+    (128, "linear", dict(enable_gravity=True, gravity=[2.0, -9.81, 0.0]), 1e-4),       # the same with two waves per beam
+    (200, "mixed", dict(fluid_density=1000.0, enable_fluid=True), 1e-4),               # truncated, padding threads
 ])
 def test_implicit_stepper_matches_oracle(n_e, kind, kw, h):
     """crb_step_implicit (implicit midpoint rule, modified Newton with A = M + h^2/4 K0 by cyclic reduction) against
@@ -1733,3 +1736,30 @@ def test_cantilever_rings_at_the_euler_bernoulli_natural_frequencies():
         band = (freq > 0.6 * f_n) & (freq < 1.4 * f_n)
         peak = freq[band][np.argmax(spec[band])]
         assert abs(peak - f_n) < 0.02 * f_n + 0.02, (peak, f_n)
+
+
+def test_implicit_reduction_levels_follow_the_step_size(monkeypatch):
+    """The cyclic reduction of A = M + h^2/4 K0 stops where its multipliers fall below the unit roundoff (5 of 8 levels at the
+    examples' h = 1e-4 for a 256-node rod, all 8 at h = 1e-3): the truncated run equals the run with every level
+    (CRB_STIFF_ALL_LEVELS=1) to rounding, for the lean and the general kernels."""
+    cols = nitinol_columns(256, "nonlinear")
+    kw = dict(fluid_density=1000.0, enable_fluid=True)
+    amps = np.array([0.05, 0.2])
+    outs = {}
+    for general in (False, True):
+        for all_levels in (False, True):
+            if general:
+                monkeypatch.setenv("CRB_DISABLE_LEAN_IMPLICIT", "1")
+            else:
+                monkeypatch.delenv("CRB_DISABLE_LEAN_IMPLICIT", raising=False)
+            if all_levels:
+                monkeypatch.setenv("CRB_STIFF_ALL_LEVELS", "1")
+            else:
+                monkeypatch.delenv("CRB_STIFF_ALL_LEVELS", raising=False)
+            ens = ensemble(cols, 2, kw)
+            ens.step_implicit(50, 1e-4, n_iter=2, impulse_amp=amps)
+            outs[(general, all_levels)] = ens.unpack_state().cpu().numpy()
+    ref = outs[(True, True)]
+    for key, got in outs.items():
+        assert np.isfinite(got).all()
+        assert_blocks(got, ref, ens.free_index, 1e-10, what=key)
