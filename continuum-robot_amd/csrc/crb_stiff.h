@@ -163,12 +163,17 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<
 // nearest-neighbour form: compile-time topology, one exchange of {q_m, a_m} for the element force and the K0 a term, the
 // merged {p, f_left} + level-0 round, levels inside the wave by DPP / ds_bpermute; the workgroup walks over beams with
 // its rows of A's tables in registers (all LV = ceil(log2 S) levels: 85 values at 256 slots, one wave per SIMD).
+#ifndef CRB_IMPLICIT_MINW5
+#define CRB_IMPLICIT_MINW5 2
+#endif
 template <typename T>
 __host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) {
     return sizeof(T) * size_t(NT + 1) * size_t(12 + 3 * (lognw > 1 ? lognw - 1 : 0));
 }
 template <typename T, int LV, int LOGNW, bool GRAV, int EM>
-__global__ void __launch_bounds__(64 << LOGNW, 1) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
+// (up to 5 levels -- the truncated reduction of small steps -- the tables are no larger than the explicit stepper's: two
+//  waves per SIMD; the full 6 ... 8 levels fill the register file at one)
+__global__ void __launch_bounds__(64 << LOGNW, LV <= 5 ? CRB_IMPLICIT_MINW5 : 1) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
     static_assert(LV >= 1, "needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
