@@ -222,6 +222,7 @@ class DynamicEulerBernoulliBeam:
             return out
 
         self.input_func = input_function
+        self._default_input_func = input_function
 
     def get_system_func(self) -> Callable:
         if self.system_func is None:
@@ -234,9 +235,38 @@ class DynamicEulerBernoulliBeam:
 
         def dynamic_system(t: float, x: np.ndarray, u: Union[np.ndarray, Callable]) -> np.ndarray:
             force = u(t) if callable(u) else u
+            # The default closures (registry forces, plain input): ONE right-hand side launch with the input added
+            # before the single mass solve -- Minv(-k + f + u) instead of Minv(-k + f) + Minv u, a rounding-level
+            # difference for half the launches of every solve_ivp RHS call.  Looked up per call, like
+            # the reference's closure: replacing system_func / input_func afterwards still takes effect.
+            if self.system_func == self._registry_rhs and self.input_func is getattr(self, "_default_input_func", None):
+                return self._fused_call(x, force)
             return self.system_func(x) + self.input_func(x, force, t)
 
         return dynamic_system
+
+    def get_composed_dynamic_system(self) -> Callable:
+        """The literal two-call composition ``system(x) + input(x, u, t)`` of the reference
+        (dynamic_beam_model.py:343-362): two launches, two mass solves."""
+        if self.system_func is None or self.input_func is None:
+            raise RuntimeError("System and input functions must be created first")
+
+        def dynamic_system(t: float, x: np.ndarray, u: Union[np.ndarray, Callable]) -> np.ndarray:
+            force = u(t) if callable(u) else u
+            return self.system_func(x) + self.input_func(x, force, t)
+
+        return dynamic_system
+
+    def _fused_call(self, x, force):
+        if not isinstance(x, np.ndarray) or not isinstance(force, np.ndarray):
+            raise ValueError("State and input must be numpy arrays")
+        if x.ndim != 1 or force.ndim != 1:
+            raise ValueError("State and input must be 1D arrays")
+        n = len(x) // 2
+        if len(force) != n:
+            raise ValueError(
+                f"Input vector length {len(force)} must match position DOFs {n}. Expected {n}, got {len(force)}")
+        return self._registry_rhs(x, force)
 
     def get_fused_dynamic_system(self) -> Callable:
         """``dynamic_system(t, x, u)`` with the registry forces AND the input in ONE right-hand side launch:

@@ -21,8 +21,8 @@ beam.create_input_func()
 n = beam.beam_model.M.shape[0]
 x = np.random.default_rng(0).normal(0, 1e-4, 2 * n)
 u = np.zeros(n); u[-2] = 0.1
-for name, dyn in (("get_dynamic_system (two launches per call)", beam.get_dynamic_system()),
-                  ("get_fused_dynamic_system (one launch per call)", beam.get_fused_dynamic_system())):
+for name, dyn in (("get_composed_dynamic_system (the literal two-call composition: two launches per call)", beam.get_composed_dynamic_system()),
+                  ("get_dynamic_system (default closures: one launch per call)", beam.get_dynamic_system())):
     for _ in range(50):
         dyn(0.0, x, u)
     t0 = time.perf_counter()

@@ -587,7 +587,7 @@ def test_fused_dynamic_system_equals_the_two_call_composition(beam_files):
                                                                              enable_gravity_effects=True))
     beam.create_system_func()
     beam.create_input_func()
-    two, one = beam.get_dynamic_system(), beam.get_fused_dynamic_system()
+    two, one = beam.get_composed_dynamic_system(), beam.get_fused_dynamic_system()
     n = beam.beam_model.M.shape[0]
     rng = np.random.default_rng(8)
     x, u = rng.normal(0, 1e-2, 2 * n), rng.normal(0, 1.0, n)
@@ -622,3 +622,30 @@ def test_reference_pool_pattern(beam_files):
     n = by["lin"][0].y.shape[0] // 2
     assert abs(by["lin"][0].y[n - 2, -1]) > 0
     assert np.linalg.norm(by["lin_fluid"][0].y[n:, -1]) < np.linalg.norm(by["lin"][0].y[n:, -1])
+
+
+@gpu
+def test_default_dynamic_system_is_one_launch_and_follows_later_replacements(beam_files):
+    """get_dynamic_system() over the default closures evaluates Minv(-k + f + u) in one launch and equals
+    the literal two-call composition to rounding; like the reference's closure it looks the functions up per call, so a
+    system function installed AFTERWARDS (create_system_func(forces_func)) takes effect in the closure already handed out."""
+    from continuum_robot.models.dynamic_beam_model import DynamicEulerBernoulliBeam
+    from continuum_robot.models.force_params import ForceParams
+
+    beam = DynamicEulerBernoulliBeam(beam_files[0], force_params=ForceParams(enable_gravity_effects=True))
+    beam.create_system_func()
+    beam.create_input_func()
+    dyn, two = beam.get_dynamic_system(), beam.get_composed_dynamic_system()
+    n = beam.beam_model.M.shape[0]
+    rng = np.random.default_rng(21)
+    x, u = rng.normal(0, 1e-2, 2 * n), rng.normal(0, 1.0, n)
+    assert_blocks(dyn(0.0, x, u), two(0.0, x, u), _free_index(beam), 1e-12)
+    with pytest.raises(ValueError, match="must match position DOFs"):
+        dyn(0.0, x, np.zeros(n + 2))
+    with pytest.raises(ValueError, match="must be numpy arrays"):
+        dyn(0.0, list(x), u)
+    extra = rng.normal(0, 1.0, n)
+    beam.create_system_func(lambda xx, t: extra)          # replaces the system function: the old closure follows
+    want = beam.get_composed_dynamic_system()(0.0, x, u)
+    assert_blocks(dyn(0.0, x, u), want, _free_index(beam), 1e-12)
+    assert np.abs(dyn(0.0, x, u) - two(0.0, x, np.zeros(n))).max() > 0
