@@ -45,6 +45,17 @@ def _columns(parameters, need_fluid):
     return cols
 
 
+class _NoContext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
+
+
 class _FusedForce:
     """Marker for a built-in force that the RHS kernel evaluates itself (drag: fluid_forces.py:103-142, gravity:
     gravity_forces.py:66-148).  It sits in the ensemble's registry like the reference's auto-registered force
@@ -129,6 +140,7 @@ class BeamEnsemble:
             raise RuntimeError("BeamEnsemble needs a HIP device: the beam stepper has no CPU path")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        self._device_index = int(self.device.index)
         self.dtype = dtype
         if isinstance(parameters, (list, tuple)):
             # heterogeneous ensemble: one parameter set per beam
@@ -138,7 +150,7 @@ class BeamEnsemble:
         else:
             self.columns = _columns(parameters, fp_of(0).enable_fluid_effects)
         fps = [fp_of(b) for b in range(n_beams)] if per_beam_fp else None
-        with torch.cuda.device(self.device):   # (plan creation selects the plan's device: keep the caller's current one)
+        with torch.cuda.device(self.device):    # (plan creation selects the plan's device: keep the caller's current one)
             self.plan = nat.Plan(
                 self.columns, n_beams=n_beams, node_bc=node_bc,
                 fluid_density=[f.fluid_density for f in fps] if fps else fp_of(0).fluid_density,
@@ -211,6 +223,14 @@ class BeamEnsemble:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _on_device(self):
+        """Context in which the library calls run: the plan's device current.  The library selects it itself
+        (hipSetDevice); when it already is the current one there is nothing to restore afterwards, and the call path of
+        a short launch saves the context manager's two device switches."""
+        if torch.cuda.current_device() == self._device_index:
+            return _NO_CONTEXT
+        return torch.cuda.device(self.device)
+
     def _dev(self, a, shape=None):
         t = torch.as_tensor(a, dtype=self.dtype, device=self.device).contiguous()
         if shape is not None and tuple(t.shape) != tuple(shape):
@@ -235,27 +255,27 @@ class BeamEnsemble:
         """reduced [B, 2n] (reference ordering [q_red ; v_red]) -> device layout [B, 2, n_node, 4]"""
         x_red = self._dev(x_red, (self.n_beams, 2 * self.n))
         out = torch.empty_like(self.state)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_pack_state(self.plan.h, self._ptr(x_red), self._ptr(out), self._stream()))
         return out
 
     def unpack_state(self, x=None) -> torch.Tensor:
         x = self.state if x is None else x
         out = torch.empty((self.n_beams, 2 * self.n), dtype=self.dtype, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_unpack_state(self.plan.h, self._ptr(x), self._ptr(out), self._stream()))
         return out
 
     def pack_vec(self, v_red) -> torch.Tensor:
         v_red = self._dev(v_red, (self.n_beams, self.n))
         out = torch.empty((self.n_beams, self.n_node, 4), dtype=self.dtype, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_pack_vec(self.plan.h, self._ptr(v_red), self._ptr(out), self._stream()))
         return out
 
     def unpack_vec(self, v) -> torch.Tensor:
         out = torch.empty((self.n_beams, self.n), dtype=self.dtype, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_unpack_vec(self.plan.h, self._ptr(v), self._ptr(out), self._stream()))
         return out
 
@@ -319,14 +339,14 @@ class BeamEnsemble:
         q = self._dev(q_red, (self.n_beams, self.n))
         x = self.pack_state(torch.cat([q, torch.zeros_like(q)], dim=1))
         k = torch.empty((self.n_beams, self.n_node, 4), dtype=self.dtype, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_internal_force(self.plan.h, self._ptr(x), self._ptr(k), self._stream()))
         return self.unpack_vec(k)
 
     def rhs_device(self, x: torch.Tensor, u: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xdot in device layout for a state (and optional force) in device layout."""
         out = torch.empty_like(x)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_rhs(self.plan.h, self._ptr(x), self._ptr(u), self._ptr(out), self._stream()))
         return out
 
@@ -377,7 +397,7 @@ class BeamEnsemble:
             rec = nat.RecordDesc(int(vel), int(node), _PARAM[param[1:-3] if vel else param], int(record_every),
                                  samples.data_ptr())
             keep.append(samples)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_step_rk4_rec(self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps),
                                                  C.byref(desc), C.byref(rec) if rec is not None else None,
                                                  C.byref(t_end), self._stream()))
@@ -420,7 +440,7 @@ class BeamEnsemble:
             rec = nat.RecordDesc(int(vel), int(node), _PARAM[param[1:-3] if vel else param], int(record_every),
                                  samples.data_ptr())
             keep.append(samples)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_step_implicit(self.plan.h, self._ptr(self.state), self.time, float(h), int(n_steps),
                                                   int(n_iter), C.byref(desc), C.byref(rec) if rec is not None else None,
                                                   C.byref(t_end), self._stream()))
@@ -519,7 +539,7 @@ class BeamEnsemble:
             grid = (float(t_eval[0]), float(t_eval[1]), int(t_eval[2]))
             ys = torch.zeros((self.n_beams, grid[2]), dtype=self.dtype, device=self.device)
             rec = nat.RecordDesc(int(vel), int(node), _PARAM[param[1:-3] if vel else param], 1, ys.data_ptr())
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_solve_rk45_eval(self.plan.h, self._ptr(self.state), self.time, float(t_end), float(rtol),
                                                     float(atol), C.byref(desc), self._ptr(h), self._ptr(stats),
                                                     int(max_steps), C.byref(rec) if rec is not None else None, grid[0],
@@ -568,7 +588,7 @@ class BeamEnsemble:
         # the whole loop is one native call (crb_step_rk4_feedback issues every launch)
         work = torch.empty((int(self._lib.crb_feedback_work_bytes(self.plan.h)),), dtype=torch.uint8, device=self.device)
         t_end = C.c_double(0.0)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_step_rk4_feedback(self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps),
                                                       self._ptr(K), self._ptr(ref), C.byref(desc), self._ptr(work),
                                                       C.byref(t_end), self._stream()))
@@ -583,7 +603,7 @@ class BeamEnsemble:
         if key not in self._plans:
             fps, per = self._fps, len(self._fps) > 1
             pick = (lambda f: [f(p) for p in fps]) if per else (lambda f: f(fps[0]))
-            with torch.cuda.device(self.device):
+            with self._on_device():
                 self._plans[key] = nat.Plan(
                     self.columns, fluid_density=pick(lambda p: p.fluid_density),
                     enable_fluid=pick(lambda p: bool(p.enable_fluid_effects and drag_on)),
@@ -620,7 +640,7 @@ class BeamEnsemble:
         u_held = None if (u is None or callable(u)) else self._dev(u, (self.n_beams, self.n))
         t = self.time
         dt = float(dt)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             for _ in range(int(n_steps)):
                 cur = self.state
                 for s, ts in enumerate((t, t + 0.5 * dt, t + 0.5 * dt, t + dt)):   # crb_step_rk4's clock convention
@@ -668,7 +688,7 @@ class BeamEnsemble:
 
     def gather(self, node: int, param: str, velocity: bool = False) -> torch.Tensor:
         out = torch.empty((self.n_beams,), dtype=self.dtype, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._on_device():
             nat.check(self._lib.crb_gather_dof(self.plan.h, self._ptr(self.state), int(velocity), int(node),
                                                _PARAM[param], self._ptr(out), self._stream()))
         return out
