@@ -213,22 +213,18 @@ hipError_t implicit_by_em(const KParams<T>& k, const StiffParams<T>& q, int grou
     return hipGetLastError();
 }
 }  // namespace
-// levels: the full count ceil(log2 S) -- 6 / 7 / 8 for one / two / four waves per beam -- or 5, where the reduction of
-// A = M + h^2/4 K0 stops for small steps (crbeam.hip: stiff_tables)
-hipError_t launch_implicit_lean(const KParams<T>& k, const StiffParams<T>& q, int groups, int levels_full, int lognw, bool grav,
+// levels: 5 ... the full count ceil(log2 S) (6 / 7 / 8 for one / two / four waves per beam): where the reduction of
+// A = M + h^2/4 K0 stops for the step size at hand (crbeam.hip: stiff_tables)
+hipError_t launch_implicit_lean(const KParams<T>& k, const StiffParams<T>& q, int groups, int levels, int lognw, bool grav,
                                 int elem_mode, hipStream_t st) {
     if constexpr (sizeof(T) == 8) {   // (fp64 plans only: crb_step_implicit refuses fp32)
-        if (levels_full == 5) {
-            if (lognw == 0) return grav ? implicit_by_em<5, 0, true>(k, q, groups, elem_mode, st) : implicit_by_em<5, 0, false>(k, q, groups, elem_mode, st);
-            if (lognw == 1) return grav ? implicit_by_em<5, 1, true>(k, q, groups, elem_mode, st) : implicit_by_em<5, 1, false>(k, q, groups, elem_mode, st);
-            if (lognw == 2) return grav ? implicit_by_em<5, 2, true>(k, q, groups, elem_mode, st) : implicit_by_em<5, 2, false>(k, q, groups, elem_mode, st);
-        }
-        if (lognw == 0 && levels_full == 6)
-            return grav ? implicit_by_em<6, 0, true>(k, q, groups, elem_mode, st) : implicit_by_em<6, 0, false>(k, q, groups, elem_mode, st);
-        if (lognw == 1 && levels_full == 7)
-            return grav ? implicit_by_em<7, 1, true>(k, q, groups, elem_mode, st) : implicit_by_em<7, 1, false>(k, q, groups, elem_mode, st);
-        if (lognw == 2 && levels_full == 8)
-            return grav ? implicit_by_em<8, 2, true>(k, q, groups, elem_mode, st) : implicit_by_em<8, 2, false>(k, q, groups, elem_mode, st);
+#define CRB_IMPL_CASE(LVV, NWW) \
+        if (levels == LVV && lognw == NWW) \
+            return grav ? implicit_by_em<LVV, NWW, true>(k, q, groups, elem_mode, st) : implicit_by_em<LVV, NWW, false>(k, q, groups, elem_mode, st);
+        CRB_IMPL_CASE(5, 0) CRB_IMPL_CASE(6, 0)
+        CRB_IMPL_CASE(5, 1) CRB_IMPL_CASE(6, 1) CRB_IMPL_CASE(7, 1)
+        CRB_IMPL_CASE(5, 2) CRB_IMPL_CASE(6, 2) CRB_IMPL_CASE(7, 2) CRB_IMPL_CASE(8, 2)
+#undef CRB_IMPL_CASE
     }
     return hipErrorInvalidValue;
 }

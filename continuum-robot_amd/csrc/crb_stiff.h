@@ -166,6 +166,10 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<
 #ifndef CRB_IMPLICIT_MINW5
 #define CRB_IMPLICIT_MINW5 2
 #endif
+// waves per SIMD the lean implicit kernels are built for: up to 5 levels the tables are no larger than the explicit
+// stepper's (two waves), 6 levels fit as well without the gravity terms (with them: >100 spilled registers), the full
+// 7 / 8 levels of long beams take the register file whole
+__host__ __device__ constexpr int implicit_lean_minw(int lv, bool grav) { return (lv <= 5 || (lv == 6 && !grav)) ? CRB_IMPLICIT_MINW5 : 1; }
 template <typename T>
 __host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) {
     return sizeof(T) * size_t(NT + 1) * size_t(12 + 3 * (lognw > 1 ? lognw - 1 : 0));
@@ -173,7 +177,7 @@ __host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) 
 template <typename T, int LV, int LOGNW, bool GRAV, int EM>
 // (up to 5 levels -- the truncated reduction of small steps -- the tables are no larger than the explicit stepper's: two
 //  waves per SIMD; the full 6 ... 8 levels fill the register file at one)
-__global__ void __launch_bounds__(64 << LOGNW, LV <= 5 ? CRB_IMPLICIT_MINW5 : 1) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
+__global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
     static_assert(LV >= 1, "needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];

@@ -1195,9 +1195,9 @@ int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
         HIP_TRY(hipMemcpyAsync(norms.data(), in.dNormScratch.p, size_t(lf) * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         while (used > 0 && norms[size_t(used) - 1] < std::ldexp(1.0, -53)) --used;
-        // (the lean kernels exist for the full count and for 5 levels; anything between runs the full count)
+        // (the lean kernels exist for 5 ... full levels)
         const bool lean_shape = p->G == 1 && p->lognw <= 2 && p->NT == (64 << p->lognw) && lf == 6 + p->lognw;
-        if (lean_shape && used != 5 && std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr) used = lf;
+        if (lean_shape && used < 5 && std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr) used = 5;
         if (used < lf) {   // the final block inverses after `used` levels
             a.fin_level = used;
             hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(in.threads), in.smem, st, a);
@@ -1236,7 +1236,7 @@ int launch_implicit(const crb_plan* p, const KParams<T>& k, const StiffParams<T>
         // one wave per SIMD (the tables of A fill the register file): 256 CUs x 4 / waves per beam workgroups are resident
         int groups = p->B;
         const bool shared = p->slot_stride == 0 && q.alv_stride == 0 && q.afin_stride == 0;
-        int resident = 256 * 4 / (1 << p->lognw) * (p->stiff_levels <= 5 ? CRB_IMPLICIT_MINW5 : 1);   // (waves per SIMD: crb_stiff.h)
+        int resident = 256 * 4 / (1 << p->lognw) * implicit_lean_minw(p->stiff_levels, grav);   // (waves per SIMD: crb_stiff.h)
         if (const char* env = std::getenv("CRB_LEAN_MAX_GROUPS")) resident = std::atoi(env) > 0 ? std::atoi(env) : resident;   // (tests)
         if (shared && groups > resident) {
             const int rounds = (groups + resident - 1) / resident;

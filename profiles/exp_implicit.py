@@ -10,6 +10,8 @@ from tests.helpers import nitinol_columns
 for ne, B, kind, kw, h in ((256, 4096, "linear", dict(enable_gravity_effects=True), 1e-4),   # (the examples' h: A's reduction stops at 5 levels)
                            (256, 4096, "nonlinear", dict(fluid_density=1000.0, enable_fluid_effects=True), 1e-4),
                            (128, 4096, "linear", dict(enable_gravity_effects=True), 1e-4),
+                           (256, 4096, "nonlinear", dict(fluid_density=1000.0, enable_fluid_effects=True), 2e-4),   # 6 levels
+                           (256, 4096, "linear", dict(enable_gravity_effects=True), 3e-4),                         # 6 - 7 levels
                            (256, 4096, "linear", dict(enable_gravity_effects=True), 1e-3),
                            (256, 4096, "nonlinear", dict(fluid_density=1000.0, enable_fluid_effects=True), 2e-4),
                            (64, 4096, "linear", dict(enable_gravity_effects=True), 1e-3),

@@ -1305,6 +1305,9 @@ def test_batched_functional_composition_matches_oracle(n_e, kind):
     (256, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), 1e-4),           # small step: A's reduction stops at 5 of 8 levels
     (128, "linear", dict(enable_gravity=True, gravity=[2.0, -9.81, 0.0]), 1e-4),       # the same with two waves per beam
     (200, "mixed", dict(fluid_density=1000.0, enable_fluid=True), 1e-4),               # truncated, padding threads
+    (256, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), 2e-4),           # 6 levels (two waves per SIMD without gravity)
+    (256, "linear", dict(enable_gravity=True), 3e-4),                                  # 6 - 7 levels with gravity
+    (100, "linear", dict(enable_gravity=True), 2e-4),                                  # two waves per beam, 6 of 7 levels
 ])
 def test_implicit_stepper_matches_oracle(n_e, kind, kw, h):
     """crb_step_implicit (implicit midpoint rule, modified Newton with A = M + h^2/4 K0 by cyclic reduction) against
