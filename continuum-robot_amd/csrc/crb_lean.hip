@@ -201,14 +201,14 @@ hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, 
 
 #if (CRB_LEAN_PART == 0 || CRB_LEAN_PART == 3) && !defined(CRB_FAST_BUILD)
 namespace {
-template <int LV, int LOGNW, bool GRAV>
+template <int LV, int LOGNW, bool GRAV, bool PACK = false>
 hipError_t implicit_by_em(const KParams<T>& k, const StiffParams<T>& q, int groups, int em, hipStream_t st) {
     const dim3 grid(groups), block(64 << LOGNW);
     const size_t smem = implicit_lean_lds_bytes<T>(64 << LOGNW, LOGNW);
     switch (em) {
-        case EM_LINEAR: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_LINEAR>), grid, block, smem, st, k, q); break;
-        case EM_NONLINEAR: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_NONLINEAR>), grid, block, smem, st, k, q); break;
-        default: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_MIXED>), grid, block, smem, st, k, q); break;
+        case EM_LINEAR: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_LINEAR, PACK>), grid, block, smem, st, k, q); break;
+        case EM_NONLINEAR: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_NONLINEAR, PACK>), grid, block, smem, st, k, q); break;
+        default: hipLaunchKernelGGL((crb_implicit_lean_kernel<T, LV, LOGNW, GRAV, EM_MIXED, PACK>), grid, block, smem, st, k, q); break;
     }
     return hipGetLastError();
 }
@@ -218,6 +218,15 @@ hipError_t implicit_by_em(const KParams<T>& k, const StiffParams<T>& q, int grou
 hipError_t launch_implicit_lean(const KParams<T>& k, const StiffParams<T>& q, int groups, int levels, int lognw, bool grav,
                                 int elem_mode, hipStream_t st) {
     if constexpr (sizeof(T) == 8) {   // (fp64 plans only: crb_step_implicit refuses fp32)
+        if (k.G > 1) {   // several beams per wave (fewer than 33 slots each: 3 ... 5 levels)
+            if (lognw != 0) return hipErrorInvalidValue;
+#define CRB_IMPL_PACK(LVV) \
+            if (levels == LVV) \
+                return grav ? implicit_by_em<LVV, 0, true, true>(k, q, groups, elem_mode, st) : implicit_by_em<LVV, 0, false, true>(k, q, groups, elem_mode, st);
+            CRB_IMPL_PACK(3) CRB_IMPL_PACK(4) CRB_IMPL_PACK(5)
+#undef CRB_IMPL_PACK
+            return hipErrorInvalidValue;
+        }
 #define CRB_IMPL_CASE(LVV, NWW) \
         if (levels == LVV && lognw == NWW) \
             return grav ? implicit_by_em<LVV, NWW, true>(k, q, groups, elem_mode, st) : implicit_by_em<LVV, NWW, false>(k, q, groups, elem_mode, st);

@@ -174,11 +174,13 @@ template <typename T>
 __host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) {
     return sizeof(T) * size_t(NT + 1) * size_t(12 + 3 * (lognw > 1 ? lognw - 1 : 0));
 }
-template <typename T, int LV, int LOGNW, bool GRAV, int EM>
-// (up to 5 levels -- the truncated reduction of small steps -- the tables are no larger than the explicit stepper's: two
-//  waves per SIMD; the full 6 ... 8 levels fill the register file at one)
+// PACK (one-wave form only): beams of fewer than 64 slots, G = 64 / S of them per wave (lane = g S + j), as in the packed
+// explicit stepper: every exchange stays a lane shift, and what a shift drags across a beam boundary is replaced by 0
+// with a select (a diverged wave-mate's Inf / NaN must not reach its neighbours through a 0 * NaN).
+template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool PACK = false>
 __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
     static_assert(LV >= 1, "needs at least one reduction level");
+    static_assert(!PACK || LOGNW == 0, "packed beams live inside one wave");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const ldsQ = reinterpret_cast<T*>(crb_smem);            // [6][NT+1]  q_m, a_m
@@ -186,13 +188,13 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
     T* const ldsB = ldsA + 6 * size_t(NT + 1);                 // [LOGNW-1][3][NT+1]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int S = p.S;
-    const int j = (lane << LOGNW) | wave;
-    const bool valid = j < S;
+    const int pg = PACK ? lane / S : 0;                         // beam of this lane inside the wave
+    const int j = PACK ? lane - pg * S : ((lane << LOGNW) | wave);
+    const bool has_slot = PACK ? (pg < p.G) : (j < S);          // this thread carries a slot (of some beam)
     auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
-    const int t_l1 = (valid && j >= 1) ? thread_of(j - 1) : NULLT;
-    const int t_r1 = (valid && j + 1 < S) ? thread_of(j + 1) : NULLT;
-    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
-    const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S;
+    const int t_l1 = (has_slot && j >= 1) ? thread_of(j - 1) : NULLT;
+    const int t_r1 = (has_slot && j + 1 < S) ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (has_slot && j + 2 < S) ? thread_of(j + 2) : NULLT;
     if (LOGNW > 0) {
         if (t < 12 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)) ldsQ[size_t(t) * (NT + 1) + NULLT] = T(0);   // the "no neighbour" entries
         __syncthreads();
@@ -206,14 +208,14 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
     bool shipped_nl = false;   // the element left of this node is a nonlinear one with the shipped f1 (no u2 term in its tangent)
     SolveCoef<T, LV> cf;
     auto load_tables = [&](int beam) {
-        if (valid) {
+        if (has_slot) {
             const SlotConst<T>* st = p.slot + size_t(beam) * p.slot_stride;
             const SlotConst<T>& sc = st[j];
             ec = sc.elem;
             dragc = (p.flags & 1u) ? sc.drag : T(0);
 #pragma unroll
             for (int c = 0; c < 3; ++c) mask[c] = sc.mask[c];
-            if (GRAV) { hm_own = sc.half_mass; hm_left = has_left ? st[j - 1].half_mass : T(0); }
+            if (GRAV) { hm_own = sc.half_mass; hm_left = j >= 1 ? st[j - 1].half_mass : T(0); }
             elem_linear_coefs<T>(ec.c, ec.kind, lin);
             shipped_nl = ec.kind == KIND_NONLINEAR && !corrected;
 #pragma unroll
@@ -237,14 +239,18 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
         }
     };
     if (shared_tables) load_tables(0);
-    const size_t node = size_t(valid ? j + p.off : 0);
     const size_t plane = size_t(p.n_node) * 4;
     const T h = T(q.h), hh = T(0.5 * q.h), alpha = T(0.25 * q.h * q.h), alpha2 = T(0.5 * q.h * q.h);
+    const int n_groups = PACK ? (p.B + p.G - 1) / p.G : p.B;
 
-    for (int beam = blockIdx.x; beam < p.B; beam += gridDim.x) {
-        if (!shared_tables) load_tables(beam);
-        const size_t xoff = size_t(beam) * 2 * plane + node * 4;
-        const size_t aoff = size_t(beam) * plane + node * 4;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int beam = PACK ? grp * p.G + pg : grp;
+        const bool valid = has_slot && (!PACK || beam < p.B);
+        const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S;
+        if (!shared_tables) load_tables(valid ? beam : 0);
+        const size_t node = size_t(valid ? j + p.off : 0);
+        const size_t xoff = size_t(valid ? beam : 0) * 2 * plane + node * 4;
+        const size_t aoff = size_t(valid ? beam : 0) * plane + node * 4;
         T q0[3] = {T(0), T(0), T(0)}, v0[3] = {T(0), T(0), T(0)}, am[3] = {T(0), T(0), T(0)}, uh[3] = {T(0), T(0), T(0)};
         T amp = T(0), gx = p.gx, gy = p.gy;
         if (valid) {
@@ -277,8 +283,11 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
                 T qL[3], zL[3], phiR = T(0);
                 if (LOGNW == 0) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { qL[c] = lane_lower<T, 1>(qm[c], lane); zL[c] = lane_lower<T, 1>(am[c], lane); }
-                    if (GRAV) phiR = lane_higher<T, 1>(qm[2], lane);
+                    for (int c = 0; c < 3; ++c) {
+                        qL[c] = lane_lower<T, 1>(qm[c], lane); zL[c] = lane_lower<T, 1>(am[c], lane);
+                        if (PACK) { qL[c] = has_left ? qL[c] : T(0); zL[c] = has_left ? zL[c] : T(0); }
+                    }
+                    if (GRAV) phiR = lane_higher<T, 1>(qm[2], lane);   // (only used under has_right)
                 } else {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { ldsQ[size_t(c) * (NT + 1) + t] = qm[c]; ldsQ[size_t(3 + c) * (NT + 1) + t] = am[c]; }
@@ -303,6 +312,7 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
                     if (LOGNW == 0) {
                         g_left[0] = lane_lower<T, 1>(g_own[0], lane);
                         g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+                        if (PACK) { g_left[0] = has_left ? g_left[0] : T(0); g_left[1] = has_left ? g_left[1] : T(0); }
                     } else {
                         gravity_segment<T>(T(0.5) * (qL[2] + qm[2]), gx, gy, hm_left, g_left);
                     }
@@ -314,9 +324,11 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
                 if (LOGNW == 0) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);   // (one wave: r first, then ITS neighbours -- see the stepper)
+                        const T fl_r1 = lane_higher<T, 1>(fl[c], lane);
+                        r[c] = pp[c] - ((!PACK || has_right) ? fl_r1 : T(0));   // (one wave: r first, then ITS neighbours -- see the stepper)
                         rlo[c] = lane_lower<T, 1>(r[c], lane);
                         rhi[c] = lane_higher<T, 1>(r[c], lane);
+                        if (PACK) { rlo[c] = has_left ? rlo[c] : T(0); rhi[c] = has_right ? rhi[c] : T(0); }
                     }
                 } else {
                     auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
@@ -331,7 +343,7 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
                     }
                 }
                 pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
-                lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, an);
+                lean_reduce_tail<T, LV, LOGNW, PACK>(cf, ldsB, t, lane, j, S, valid, r, an);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) am[c] = an[c];
                 // (LOGNW == 1: round A's columns are rewritten only after the next iteration's q exchange barrier;

@@ -1198,6 +1198,9 @@ int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
         // (the lean kernels exist for 5 ... full levels)
         const bool lean_shape = p->G == 1 && p->lognw <= 2 && p->NT == (64 << p->lognw) && lf == 6 + p->lognw;
         if (lean_shape && used < 5 && std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr) used = 5;
+        // (several beams per wave: the packed lean kernels exist for 3 ... 5 levels)
+        const bool pack_shape = p->G > 1 && p->lognw == 0 && p->NT == 64 && lf >= 3 && lf <= 5;
+        if (pack_shape && used < 3) used = 3;
         if (used < lf) {   // the final block inverses after `used` levels
             a.fin_level = used;
             hipLaunchKernelGGL((crb_assemble_kernel<T>), dim3(nd), dim3(in.threads), in.smem, st, a);
@@ -1231,10 +1234,13 @@ int launch_implicit(const crb_plan* p, const KParams<T>& k, const StiffParams<T>
 #else
     // the lean form: one beam per workgroup of 1 / 2 / 4 waves with ALL its reduction levels, gravity absent or canonical
     const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
-    if (p->G == 1 && p->lognw <= 2 && p->NT == (64 << p->lognw) && p->levels_full == 6 + p->lognw && (!grav || p->canonical_gravity) &&
+    const bool one_per_group = p->G == 1 && p->lognw <= 2 && p->NT == (64 << p->lognw) && p->levels_full == 6 + p->lognw;
+    const bool packed = p->G > 1 && p->lognw == 0 && p->NT == 64 && p->levels_full >= 3 && p->levels_full <= 5 && p->stiff_levels >= 3 &&
+                        std::getenv("CRB_DISABLE_LEAN_PACK") == nullptr;
+    if ((one_per_group || packed) && (!grav || p->canonical_gravity) &&
         std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr) {
         // one wave per SIMD (the tables of A fill the register file): 256 CUs x 4 / waves per beam workgroups are resident
-        int groups = p->B;
+        int groups = (p->B + p->G - 1) / p->G;
         const bool shared = p->slot_stride == 0 && q.alv_stride == 0 && q.afin_stride == 0;
         int resident = 256 * 4 / (1 << p->lognw) * implicit_lean_minw(p->stiff_levels, grav);   // (waves per SIMD: crb_stiff.h)
         if (const char* env = std::getenv("CRB_LEAN_MAX_GROUPS")) resident = std::atoi(env) > 0 ? std::atoi(env) : resident;   // (tests)

@@ -1448,7 +1448,10 @@ def test_implicit_stepper_integrates_config1_for_the_examples_full_second(golden
 
 @pytest.mark.parametrize("n_e,kind,kw", [(64, "linear", dict(enable_gravity=True)),
                                           (100, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True)),
-                                          (256, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True))])
+                                          (256, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True)),
+                                          (10, "linear", dict(enable_gravity=True)),                                # six beams per wave
+                                          (5, "mixed", dict(fluid_density=1000.0, enable_fluid=True)),              # twelve, 3 levels
+                                          (30, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True))])   # two, 5 levels
 def test_implicit_lean_kernel_equals_the_general_one(n_e, kind, kw, monkeypatch):
     """crb_implicit_lean_kernel (lean exchange structure, workgroups walking over beams: 7 beams on 3 workgroups here)
     against crb_implicit_kernel (general kernel machinery, CRB_DISABLE_LEAN_IMPLICIT) and against the oracle, with
@@ -1766,3 +1769,30 @@ def test_implicit_reduction_levels_follow_the_step_size(monkeypatch):
     for key, got in outs.items():
         assert np.isfinite(got).all()
         assert_blocks(got, ref, ens.free_index, 1e-10, what=key)
+
+
+@pytest.mark.parametrize("poison", ["nan", "inf"])
+def test_packed_implicit_beams_are_isolated_from_a_diverged_wave_mate(poison):
+    """Several short beams share a wave in the packed lean implicit kernel; a beam whose state is non-finite must not
+    reach its wave-mates (selects at the beam boundaries, not zero weights): every other beam is bitwise equal to the run
+    without the poisoned one."""
+    cols = nitinol_columns(10, "linear")
+    kw = dict(enable_gravity=True)
+    B = 13
+    rng = np.random.default_rng(77)
+    x0 = rng.normal(0.0, 1e-6, (B, 60))
+    amps = 0.05 * (1.0 + np.arange(B) / B)
+    a = ensemble(cols, B, kw)
+    a.set_state(x0)
+    a.step_implicit(30, 1e-4, n_iter=2, impulse_amp=amps)
+    want = a.unpack_state()
+    bad = [3, 8]
+    x1 = x0.copy()
+    x1[bad, 5] = np.nan if poison == "nan" else np.inf
+    b = ensemble(cols, B, kw)
+    b.set_state(x1)
+    b.step_implicit(30, 1e-4, n_iter=2, impulse_amp=amps)
+    got = b.unpack_state()
+    good = [k for k in range(B) if k not in bad]
+    assert torch.equal(got[good], want[good])
+    assert not bool(torch.isfinite(got[bad]).all())
