@@ -485,7 +485,7 @@ def worker(args):
         achieved = algo_bytes_launch / avg_launch_s / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "crb_implicit_kernel" if cfg.get("implicit") else "crb_step_lean_kernel",
+                    "kernel": "crb_implicit_lean_kernel" if cfg.get("implicit") else "crb_step_lean_kernel",
                     "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_launch,
                     "valu_issue_frac": None}
     else:
