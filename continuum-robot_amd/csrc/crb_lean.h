@@ -93,6 +93,9 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 #ifndef CRB_SOA
 #define CRB_SOA 1
 #endif
+#ifndef CRB_UNMERGED   // fp64 beams of several waves form r before exchanging it (0: the merged round {qn, p, fl})
+#define CRB_UNMERGED 1
+#endif
 #ifndef CRB_SOA_F32   // fp32 round A as 4-byte columns instead of 16-byte records (experiment switch)
 #define CRB_SOA_F32 0
 #endif
@@ -507,7 +510,23 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
                 }
             } else {
                 T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT + 1) * RN : 0);
-                if (SOA) {
+                if (SOA && CRB_UNMERGED) {
+                    // r first (one exchange of {qn, fl}), then ITS stride-1 neighbours (a second one): the same 9 stores +
+                    // 12 loads as the merged round {qn, p, fl}, 6 subtractions less, one barrier more -- the fp64 stepper is
+                    // bound by vector-ALU issue, not by its barriers: 27.72 -> 27.18 us per step at 4096 x 256
+                    recA(bufA, t, 0) = qn[0]; recA(bufA, t, 1) = qn[1]; recA(bufA, t, 2) = qn[2];
+                    recA(bufA, t, 6) = fl[0]; recA(bufA, t, 7) = fl[1]; recA(bufA, t, 8) = fl[2];
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) r[c] = pp[c] - recA(bufA, t_r1, 6 + c);
+                    if (GRAV) phiR = recA(bufA, t_r1, 2);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) qL[c] = recA(bufA, t_l1, c);
+                    recA(bufA, t, 3) = r[0]; recA(bufA, t, 4) = r[1]; recA(bufA, t, 5) = r[2];
+                    __syncthreads();
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { rlo[c] = recA(bufA, t_l1, 3 + c); rhi[c] = recA(bufA, t_r1, 3 + c); }
+                } else if (SOA) {
                     recA(bufA, t, 0) = qn[0]; recA(bufA, t, 1) = qn[1]; recA(bufA, t, 2) = qn[2];
                     recA(bufA, t, 3) = pp[0]; recA(bufA, t, 4) = pp[1]; recA(bufA, t, 5) = pp[2];
                     recA(bufA, t, 6) = fl[0]; recA(bufA, t, 7) = fl[1]; recA(bufA, t, 8) = fl[2];
