@@ -93,6 +93,9 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 #ifndef CRB_SOA
 #define CRB_SOA 1
 #endif
+#ifndef CRB_UNMERGED_F32   // the same for fp32 records (0: the merged round): 3 + 4 LDS instructions instead of 3 + 5
+#define CRB_UNMERGED_F32 1
+#endif
 #ifndef CRB_UNMERGED   // fp64 beams of several waves form r before exchanging it (0: the merged round {qn, p, fl})
 #define CRB_UNMERGED 1
 #endif
@@ -540,6 +543,24 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
                     if (GRAV) phiR = recA(bufA, t_r1, 2);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) qL[c] = recA(bufA, t_l1, c);
+                } else if (sizeof(T) == 4 && CRB_UNMERGED_F32) {
+                    // fp32 records, r first: [qn0 qn1 qn2 - | fl0 fl1 fl2 -] out, the left neighbour's word 0 and the right
+                    // one's word 1 (and its phi) in; then [r0 r1 r2 -] (word 2) out and both neighbours' in: 3 stores + 4 loads
+                    typedef T rec4 __attribute__((ext_vector_type(4)));
+                    rec4* recs = reinterpret_cast<rec4*>(bufA);
+                    constexpr int W = RN / 4;   // 16-byte words per record
+                    recs[size_t(t) * W + 0] = rec4{qn[0], qn[1], qn[2], T(0)};
+                    recs[size_t(t) * W + 1] = rec4{fl[0], fl[1], fl[2], T(0)};
+                    __syncthreads();
+                    const rec4 lq = recs[size_t(t_l1) * W + 0], rf = recs[size_t(t_r1) * W + 1];
+                    if (GRAV) phiR = recs[size_t(t_r1) * W + 0][2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { qL[c] = lq[c]; r[c] = pp[c] - rf[c]; }
+                    recs[size_t(t) * W + 2] = rec4{r[0], r[1], r[2], T(0)};
+                    __syncthreads();
+                    const rec4 rl = recs[size_t(t_l1) * W + 2], rr = recs[size_t(t_r1) * W + 2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { rlo[c] = rl[c]; rhi[c] = rr[c]; }
                 } else {
                 typedef typename Vec16<T>::type vec;
                 // record: fp32 [qn0 qn1 qn2 - | p0 p1 p2 - | fl0 fl1 fl2 -] (each neighbour's read is whole 16-byte words:
