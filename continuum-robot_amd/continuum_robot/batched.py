@@ -449,16 +449,24 @@ class BeamEnsemble:
         return (self.time, samples) if record is not None else self.time
 
     def solve_ivp(self, t_span, t_eval, method: str = "LSODA", impulse_amp=None, impulse_duration: float = 0.01,
-                  impulse_index: int = -2, held_force=None, substeps: int = 10, rtol: float = 1e-3, atol: float = 1e-6):
+                  impulse_index: int = -2, held_force=None, substeps: Union[int, str, None] = None,
+                  rtol: float = 1e-3, atol: float = 1e-6, control: str = "all"):
         """The examples' integration call for the whole ensemble (examples/example_utilities.py:153-159:
         ``solve_ivp(f, t_span, x0, method="LSODA", t_eval=np.arange(t0, t1, DT))``) from the RESIDENT state, with the
         examples' forcing.  ``t_eval`` must be a uniform grid starting at ``t_span[0]`` (what ``np.arange`` gives).
 
         method   "LSODA" / "BDF" / "Radau" (the stiff solvers the examples use): the A-stable implicit stepper
-                 (``step_implicit``) with ``substeps`` steps per ``t_eval`` interval -- DT = 1e-3 with 10 substeps is
-                 h = 1e-4 s;   "RK45": ``solve_rk45`` (scipy's algorithm, per-beam step control, rtol / atol) with
+                 (``step_implicit``).  ``substeps="auto"`` (the default, as the reference's call means it): the step size
+                 is CONTROLLED by ``rtol`` / ``atol`` (``_solve_implicit_controlled``: every interval is integrated with
+                 h and with h / 2, the difference is the error estimate, all beams take the step the worst one needs;
+                 at the examples' default tolerances the whole state, velocities included, lands as close to a
+                 tight-tolerance LSODA run as LSODA itself does at these tolerances -- h = 3 ... 6 us for the 10-element
+                 example).  An integer: that many steps per ``t_eval`` interval, no control, one launch for the whole
+                 span -- DT = 1e-3 with 10 substeps is h = 1e-4 s (displacements within the examples' tolerance band,
+                 velocity content of the unresolved modes not);
+                 "RK45": ``solve_rk45`` (scipy's algorithm, per-beam step control, rtol / atol) with
                  its dense output on the grid;   "RK4": the fused explicit stepper with ``substeps`` steps per interval
-                 (stable for dt <= ~7e-5 s).
+                 (default 10; stable for dt <= ~7e-5 s).
         Returns an object with ``t`` [n_t] and ``y`` [B, 2n, n_t] (``y[b]`` is the reference's ``sol.y`` of beam b,
         first column = the state at ``t_span[0]``), ``success``, ``method``; the resident state ends at the last
         ``t_eval`` point reached by whole intervals (RK45: at ``t_span[1]``)."""
@@ -472,15 +480,25 @@ class BeamEnsemble:
         self.time = float(t_span[0])
         first = self.unpack_state().unsqueeze(0)                       # the state at t_span[0]
         kind = method.upper()
+        if substeps is None:
+            substeps = "auto" if kind in ("LSODA", "BDF", "RADAU", "IMPLICIT") else 10
+        elif not isinstance(substeps, str) and int(substeps) < 1:
+            raise ValueError('substeps must be a positive integer or "auto"')
         kw = dict(impulse_amp=impulse_amp, impulse_duration=impulse_duration, impulse_index=impulse_index,
                   held_force=held_force)
         if n_t == 1:
             ys = first
+        elif kind in ("LSODA", "BDF", "RADAU", "IMPLICIT") and isinstance(substeps, str):
+            if substeps != "auto":
+                raise ValueError('substeps must be a positive integer or "auto"')
+            ys, used = self._solve_implicit_controlled(float(t_span[0]), dt_eval, n_t, first, rtol, atol, control, kw)
         elif kind in ("LSODA", "BDF", "RADAU", "IMPLICIT"):
             _, snaps = self.step_implicit((n_t - 1) * int(substeps), dt_eval / int(substeps), record="all",
                                           record_every=int(substeps), **kw)
             ys = torch.cat([first, self.unpack_snapshots(snaps)], dim=0)
         elif kind == "RK4":
+            if isinstance(substeps, str):
+                raise ValueError("RK4 takes an integer number of substeps")
             _, snaps = self.step((n_t - 1) * int(substeps), dt_eval / int(substeps), record="all",
                                  record_every=int(substeps), **kw)
             ys = torch.cat([first, self.unpack_snapshots(snaps)], dim=0)
@@ -498,7 +516,58 @@ class BeamEnsemble:
 
         sol = OdeResult()
         sol.t, sol.y, sol.success, sol.method = t_eval.copy(), ys.permute(1, 2, 0).contiguous(), True, kind
+        if isinstance(substeps, str) and kind in ("LSODA", "BDF", "RADAU", "IMPLICIT") and n_t > 1:
+            sol.substeps = used      # steps per t_eval interval that the controller accepted
         return sol
+
+    def _solve_implicit_controlled(self, t0, dt_eval, n_t, first, rtol, atol, control, kw, max_substeps=1 << 14):
+        """Implicit midpoint rule with step-size control by step doubling: every ``t_eval`` interval is integrated
+        from the same state with m steps and with 2m steps; for this second-order scheme (fine - coarse) / 3
+        estimates the error of the fine solution, which is measured like scipy measures its own (RMS over a beam's state
+        of err / (atol + rtol |y|), tolerances of the reference's call, example_utilities.py:153-159 /
+        lqr_control.py:117-125) -- the worst beam decides for the ensemble.  Above 1 the interval is repeated with
+        twice the steps (the fine solution becomes the coarse one), the accepted solution is the fine one; an estimate
+        far below 1 halves m for the next interval.  ``control="positions"`` measures the position half of the state
+        only (velocity components of modes far above 1 / h keep their amplitude but not their phase, which the full
+        norm answers with the small steps LSODA itself takes).  Returns (states [n_t, B, 2n], accepted m per interval)."""
+        if control not in ("all", "positions"):
+            raise ValueError('control must be "all" or "positions"')
+        n_dof = torch.as_tensor(np.asarray(self.n_per_beam, dtype=np.float64) * (2.0 if control == "all" else 1.0),
+                                dtype=torch.float64, device=self.device)
+        rows = slice(None) if control == "all" else slice(0, 1)
+
+        def estimate(fine, coarse, start):
+            scale = atol + rtol * torch.maximum(fine[:, rows].abs(), start[:, rows].abs())
+            e = ((fine[:, rows] - coarse[:, rows]) / (3.0 * scale)).double()
+            return float(torch.sqrt((e * e).sum(dim=(1, 2, 3)) / n_dof).max().item())
+
+        def run(start, t_start, m):
+            self.state = start.clone()
+            self.step_implicit(m, dt_eval / m, t0=t_start, **kw)
+            return self.state
+
+        m = max(1, int(np.ceil(dt_eval / 1e-4)))
+        out, used = [first], []
+        for k in range(n_t - 1):
+            t_k = t0 + k * dt_eval
+            start = self.state
+            coarse = run(start, t_k, m)
+            while True:
+                fine = run(start, t_k, 2 * m)
+                err = estimate(fine, coarse, start)
+                if err <= 1.0:
+                    break
+                m, coarse = 2 * m, fine
+                if 2 * m > max_substeps:
+                    raise RuntimeError(f"solve_ivp: the tolerances ask for more than {max_substeps} steps per t_eval interval "
+                                       f"at t = {t_k:.6g} s (error estimate {err:.3g})")
+            used.append(2 * m)
+            self.state = fine
+            self.time = t0 + (k + 1) * dt_eval
+            out.append(self.unpack_state().unsqueeze(0))
+            if err < 0.05 and m > 1:      # second order: half the steps would still pass (4 x the estimate < 1 with margin)
+                m //= 2
+        return torch.cat(out, dim=0), used
 
     def solve_rk45(self, t_end: float, rtol: float = 1e-3, atol: float = 1e-6, impulse_amp=None,
                    impulse_duration: float = 0.01, impulse_index: int = -2, held_force=None,

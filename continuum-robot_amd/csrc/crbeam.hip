@@ -71,10 +71,16 @@ struct crb_plan {
     // implicit stepper: cyclic-reduction tables of A = M + alpha K0 for the step size last used (all levels: A is not
     // as diagonally dominant as M, nothing is truncated)
     AsmInputs* asm_in = nullptr;
-    mutable void* d_alevels = nullptr;   // [nd][levels_full][S][10]
+    mutable void* d_alevels = nullptr;   // [nd][levels_full][S][10]   (the set in use: one of `stiff_sets`)
     mutable void* d_afinal = nullptr;    // [nd][S][6]
     mutable double stiff_alpha = 0.0;    // alpha the tables above were built for (0 = none yet)
     mutable int stiff_levels = 0;        // reduction levels of A that the implicit kernels run (the rest are below roundoff)
+    // the table sets of the step sizes used last (a step-size controller alternates between h and h / 2: without this
+    // every change would factorise again and synchronise the stream); the oldest set is overwritten
+    struct StiffSet { void* lev = nullptr; void* fin = nullptr; double alpha = 0.0; int levels = 0; unsigned long long used = 0; };
+    static constexpr int N_STIFF_SETS = 4;
+    mutable StiffSet stiff_sets[N_STIFF_SETS];
+    mutable unsigned long long stiff_clock = 0;
     // host-vector entry points (crb_rhs_host): full -> reduced map on the device, pinned staging, a stream of the plan's own
     mutable int32_t* d_red_map = nullptr;
     mutable double* h_stage = nullptr;   // pinned + mapped: [2n | n | 2n] doubles (x, u, out)
@@ -672,8 +678,7 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         (void)hipFree(p->d_row_off);
         (void)hipFree(p->d_gvec);
         (void)hipFree(p->d_n_state);
-        (void)hipFree(p->d_alevels);
-        (void)hipFree(p->d_afinal);
+        for (auto& set : p->stiff_sets) { (void)hipFree(set.lev); (void)hipFree(set.fin); }
         (void)hipFree(p->d_red_map);
         if (p->h_stage) (void)hipHostFree(p->h_stage);
         if (p->host_stream) (void)hipStreamDestroy(p->host_stream);
@@ -1174,11 +1179,31 @@ int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
     if (p->stiff_alpha == alpha && p->d_alevels) return CRB_OK;
     AsmInputs& in = *p->asm_in;
     const int S = p->S, lf = p->levels_full, nd = in.nd;
-    if (!p->d_alevels) {
-        HIP_TRY(hipMalloc(&p->d_alevels, size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
-        HIP_TRY(hipMalloc(&p->d_afinal, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)));
-        if (in.dNormScratch.alloc(size_t(lf > 0 ? lf : 1))) return fail(CRB_EHIP, "crb_step_implicit: device allocation failed");
+    // a set built earlier for this step size, else the least recently used one (work queued on `st` that still reads
+    // the overwritten set is ordered before the assembly launched below on the same stream)
+    crb_plan::StiffSet* set = nullptr;
+    for (auto& c : p->stiff_sets)
+        if (c.lev && c.alpha == alpha) set = &c;
+    const bool hit = set != nullptr;
+    if (!set) {
+        set = &p->stiff_sets[0];
+        for (auto& c : p->stiff_sets)
+            if (c.used < set->used) set = &c;
     }
+    if (!set->lev) {
+        HIP_TRY(hipMalloc(&set->lev, size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
+        HIP_TRY(hipMalloc(&set->fin, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)));
+        if (!in.dNormScratch.p && in.dNormScratch.alloc(size_t(lf > 0 ? lf : 1))) return fail(CRB_EHIP, "crb_step_implicit: device allocation failed");
+    }
+    set->used = ++p->stiff_clock;
+    p->d_alevels = set->lev;
+    p->d_afinal = set->fin;
+    if (hit) {
+        p->stiff_levels = set->levels;
+        p->stiff_alpha = alpha;
+        return CRB_OK;
+    }
+    set->alpha = 0.0;   // (not valid until the build below has been queued)
     AsmParams a = in.a;
     a.alpha = alpha;
     a.slot_out = nullptr; a.lv64 = nullptr; a.fin64_all = nullptr; a.blocks0 = nullptr;
@@ -1209,6 +1234,8 @@ int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
     }
     p->stiff_levels = used;
     p->stiff_alpha = alpha;
+    set->levels = used;
+    set->alpha = alpha;
     return CRB_OK;
 }
 

@@ -1498,7 +1498,7 @@ def test_examples_solve_ivp_call_for_an_ensemble(golden):
     ens = ensemble(cols, 2, kw)
     n = ens.n
     t_eval = np.arange(0.0, 0.3005, 0.001)
-    sol = ens.solve_ivp((0.0, 0.3005), t_eval, method="LSODA", impulse_amp=np.full(2, 0.1))
+    sol = ens.solve_ivp((0.0, 0.3005), t_eval, method="LSODA", substeps=10, impulse_amp=np.full(2, 0.1))
     assert sol.t.shape == (301,) and tuple(sol.y.shape) == (2, 2 * n, 301) and sol.success
     y = sol.y.cpu().numpy()
     assert np.all(y[:, :, 0] == 0.0)                                   # first column: the initial state
@@ -1522,6 +1522,54 @@ def test_examples_solve_ivp_call_for_an_ensemble(golden):
         ens.solve_ivp((0.0, 1.0), np.array([0.0, 0.1, 0.3]))
     with pytest.raises(ValueError, match="unknown method"):
         ens.solve_ivp((0.0, 1.0), np.arange(0, 1, 0.1), method="Euler")
+
+
+@pytest.mark.parametrize("name", ["lin10_grav", "lin6_fluid", "mixed6_fluid"])
+def test_solve_ivp_controls_the_step_by_the_tolerances(golden, name):
+    """``solve_ivp(method="LSODA")`` without ``substeps``: the step size follows rtol / atol (step doubling on the implicit
+    midpoint rule), as the reference's call means it (examples/example_utilities.py:153-159, default tolerances).  The
+    yardstick is the reference's own integrator: golden G8 holds scipy LSODA over the REFERENCE RHS at tight tolerances
+    (1e-10 / 1e-12) and at the defaults.  In units of the default tolerance band (1e-6 + 1e-3 |y|) the controlled run has
+    to land every position DOF inside the band and be, over the WHOLE state (velocities of the stiff modes included),
+    about as close to the tight run as default-tolerance LSODA is (measured: RMS 7 ... 49 against LSODA's 17 ... 55, largest
+    entry 34 ... 340 against 70 ... 190) -- which the uncontrolled h = 1e-4 run is not (RMS 350 ... 690).  A tolerance
+    1000 times tighter brings the error down by about as much."""
+    z = golden["g8_lsoda"]
+    cols, kw = beam_columns(z, name), force_kwargs(z, name)
+    times, tight, dflt = z[name + "/times"], z[name + "/x_tight"], z[name + "/x_default_tol"]
+    amp, T = float(z[name + "/amp"]), float(z[name + "/times"][-1])
+    t_eval = np.arange(0.0, T + 0.0005, 0.001)
+
+    def scaled_errors(**tol):
+        ens = ensemble(cols, 2, kw)
+        sol = ens.solve_ivp((0.0, T + 0.0005), t_eval, method="LSODA", impulse_amp=np.full(2, amp), **tol)
+        y = sol.y.cpu().numpy()
+        assert np.array_equal(y[0], y[1]) and abs(ens.time - t_eval[-1]) < 1e-9 and len(sol.substeps) == t_eval.size - 1
+        out = []
+        for ti, t in enumerate(times):
+            band = 1e-6 + 1e-3 * np.abs(tight[ti])
+            out.append((np.abs(y[0][:, int(round(t / 0.001))] - tight[ti]) / band, np.abs(dflt[ti] - tight[ti]) / band))
+        return ens.n, out, sol.substeps
+
+    n, errs, used = scaled_errors()
+    assert min(used) >= 40        # (h <= 2.5e-5 s: the controller does resolve the stiff modes, as LSODA does)
+    for ours, lsoda in errs:
+        assert ours[:n].max() < 1.0, (name, ours[:n].max())
+        assert np.sqrt((ours ** 2).mean()) < 2.0 * np.sqrt((lsoda ** 2).mean()), name
+        assert ours.max() < 4.0 * lsoda.max(), (name, ours.max(), lsoda.max())
+    _, errs_t, used_t = scaled_errors(rtol=1e-6, atol=1e-9)
+    assert max(used_t) > 8 * max(used)
+    for (ours_t, _), (ours, _) in zip(errs_t, errs):
+        assert ours_t.max() < 2e-2 * max(ours.max(), 50.0), (name, ours_t.max(), ours.max())
+    ens = ensemble(cols, 2, kw)
+    with pytest.raises(ValueError, match="substeps"):
+        ens.solve_ivp((0.0, 0.01), t_eval[:11], method="LSODA", substeps="fine")
+    with pytest.raises(ValueError, match="control"):
+        ens.solve_ivp((0.0, 0.01), t_eval[:11], method="LSODA", control="some")
+    with pytest.raises(ValueError, match="integer"):
+        ens.solve_ivp((0.0, 0.01), t_eval[:11], method="RK4", substeps="auto")
+    with pytest.raises(RuntimeError, match="tolerances ask for more"):
+        ens.solve_ivp((0.0, 0.002), t_eval[:3], method="LSODA", rtol=1e-15, atol=1e-18, impulse_amp=np.full(2, amp))
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CRB_FUZZ_MIXED_N", "12"))))   # CRB_FUZZ_MIXED_N=200 for a long hunt
