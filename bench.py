@@ -427,8 +427,8 @@ def worker(args):
     wall, gathered = timed_rollout()
     walls.append(wall)
     # a region shorter than 50 ms is not a measurement to rank kernels by: repeat it (every rank derives the same
-    # count from the max-reduced first wall) and report the median
-    repeats = args.repeats if args.repeats > 0 else max(1, min(1000, int(np.ceil(MIN_TIMED_S / max(wall, 1e-6)))))
+    # count from the max-reduced first wall; the first repeat is the slowest, hence the 25 % margin) and report the median
+    repeats = args.repeats if args.repeats > 0 else max(1, min(1000, int(np.ceil(1.25 * MIN_TIMED_S / max(wall, 1e-6)))))
     for _ in range(repeats - 1):
         wall, gathered = timed_rollout()
         walls.append(wall)
