@@ -450,7 +450,7 @@ class BeamEnsemble:
 
     def solve_ivp(self, t_span, t_eval, method: str = "LSODA", impulse_amp=None, impulse_duration: float = 0.01,
                   impulse_index: int = -2, held_force=None, substeps: Union[int, str, None] = None,
-                  rtol: float = 1e-3, atol: float = 1e-6, control: str = "all"):
+                  rtol: float = 1e-3, atol: float = 1e-6, control: str = "all", gain=None, reference=None):
         """The examples' integration call for the whole ensemble (examples/example_utilities.py:153-159:
         ``solve_ivp(f, t_span, x0, method="LSODA", t_eval=np.arange(t0, t1, DT))``) from the RESIDENT state, with the
         examples' forcing.  ``t_eval`` must be a uniform grid starting at ``t_span[0]`` (what ``np.arange`` gives).
@@ -467,6 +467,11 @@ class BeamEnsemble:
                  "RK45": ``solve_rk45`` (scipy's algorithm, per-beam step control, rtol / atol) with
                  its dense output on the grid;   "RK4": the fused explicit stepper with ``substeps`` steps per interval
                  (default 10; stable for dt <= ~7e-5 s).
+        gain     [n, 2n]: the CLOSED loop of examples/lqr_control.py:94-125 (``u = K (reference - x)`` inside the RHS, default
+                 reference 0, plus the impulse) -- RK4 with the feedback evaluated in every stage (``step_feedback``) for
+                 every method except "RK45"; the stiff methods choose its step by ``rtol`` / ``atol`` with the same
+                 controller ((fine - coarse) / 15 for the fourth-order scheme; a step beyond RK4's stability limit shows
+                 as a failed estimate and is halved), "RK4" takes ``substeps`` as given.
         Returns an object with ``t`` [n_t] and ``y`` [B, 2n, n_t] (``y[b]`` is the reference's ``sol.y`` of beam b,
         first column = the state at ``t_span[0]``), ``success``, ``method``; the resident state ends at the last
         ``t_eval`` point reached by whole intervals (RK45: at ``t_span[1]``)."""
@@ -486,12 +491,47 @@ class BeamEnsemble:
             raise ValueError('substeps must be a positive integer or "auto"')
         kw = dict(impulse_amp=impulse_amp, impulse_duration=impulse_duration, impulse_index=impulse_index,
                   held_force=held_force)
+        stiff = kind in ("LSODA", "BDF", "RADAU", "IMPLICIT")
+        if isinstance(substeps, str) and substeps != "auto":
+            raise ValueError('substeps must be a positive integer or "auto"')
+        if gain is not None:
+            if held_force is not None or kind == "RK45" or not (stiff or kind == "RK4"):
+                raise ValueError("the closed loop (gain=...) runs with the stiff methods or RK4, without a held force")
+            fkw = dict(reference=reference, impulse_amp=impulse_amp, impulse_duration=impulse_duration, impulse_index=impulse_index)
+
+            def advance(m, h, t_start, forced=None):
+                self.step_feedback(m, h, gain, t0=t_start, **(fkw if forced is None else forced_input(fkw, forced)))
+        else:
+            def advance(m, h, t_start, forced=None):
+                self.step_implicit(m, h, t0=t_start, **(kw if forced is None else forced_input(kw, forced)))
+
+        def forced_input(args, on):
+            # the controller integrates between breakpoints of the input: inside a piece the impulse is simply on or off
+            # (a stage time that lands ON the switch would otherwise put a first-order error into a fourth-order step)
+            args = dict(args)
+            if on:
+                args["impulse_duration"] = float("inf")
+            else:
+                args["impulse_amp"] = None
+            return args
+
+        t_switch = None if impulse_amp is None else float(impulse_duration)
         if n_t == 1:
             ys = first
-        elif kind in ("LSODA", "BDF", "RADAU", "IMPLICIT") and isinstance(substeps, str):
-            if substeps != "auto":
-                raise ValueError('substeps must be a positive integer or "auto"')
-            ys, used = self._solve_implicit_controlled(float(t_span[0]), dt_eval, n_t, first, rtol, atol, control, kw)
+        elif gain is not None and not isinstance(substeps, str):
+            out = [first]
+            for k in range(n_t - 1):
+                advance(int(substeps), dt_eval / int(substeps), float(t_span[0]) + k * dt_eval)
+                out.append(self.unpack_state().unsqueeze(0))
+            self.time = float(t_span[0]) + (n_t - 1) * dt_eval
+            ys = torch.cat(out, dim=0)
+        elif gain is not None:
+            # (RK4 is only conditionally stable: start near the closed loop's limit for the Nitinol examples, 8.6e-6 s)
+            ys, used = self._solve_controlled(advance, 4, max(1, int(np.ceil(dt_eval / 5e-6))), float(t_span[0]), dt_eval, n_t,
+                                              first, rtol, atol, control, t_switch)
+        elif stiff and isinstance(substeps, str):
+            ys, used = self._solve_controlled(advance, 2, max(1, int(np.ceil(dt_eval / 1e-4))), float(t_span[0]), dt_eval, n_t,
+                                              first, rtol, atol, control, t_switch)
         elif kind in ("LSODA", "BDF", "RADAU", "IMPLICIT"):
             _, snaps = self.step_implicit((n_t - 1) * int(substeps), dt_eval / int(substeps), record="all",
                                           record_every=int(substeps), **kw)
@@ -516,18 +556,23 @@ class BeamEnsemble:
 
         sol = OdeResult()
         sol.t, sol.y, sol.success, sol.method = t_eval.copy(), ys.permute(1, 2, 0).contiguous(), True, kind
-        if isinstance(substeps, str) and kind in ("LSODA", "BDF", "RADAU", "IMPLICIT") and n_t > 1:
+        if isinstance(substeps, str) and stiff and n_t > 1:
             sol.substeps = used      # steps per t_eval interval that the controller accepted
         return sol
 
-    def _solve_implicit_controlled(self, t0, dt_eval, n_t, first, rtol, atol, control, kw, max_substeps=1 << 14):
-        """Implicit midpoint rule with step-size control by step doubling: every ``t_eval`` interval is integrated
-        from the same state with m steps and with 2m steps; for this second-order scheme (fine - coarse) / 3
+    def _solve_controlled(self, advance, order, m_first, t0, dt_eval, n_t, first, rtol, atol, control, t_switch=None,
+                          max_substeps=1 << 14):
+        """Step-size control by step doubling for a fixed-step scheme of the given order (``advance(m, h, t, on)`` takes m
+        steps of size h from the resident state at time t with the impulse on or off: the implicit midpoint rule, order
+        2, or the closed-loop RK4, order 4): every ``t_eval`` interval -- cut in two at ``t_switch``, the end of the
+        impulse, when that falls inside it -- is integrated from the same state with m steps and with 2m steps;
+        (fine - coarse) / (2^order - 1)
         estimates the error of the fine solution, which is measured like scipy measures its own (RMS over a beam's state
         of err / (atol + rtol |y|), tolerances of the reference's call, example_utilities.py:153-159 /
         lqr_control.py:117-125) -- the worst beam decides for the ensemble.  Above 1 the interval is repeated with
-        twice the steps (the fine solution becomes the coarse one), the accepted solution is the fine one; an estimate
-        far below 1 halves m for the next interval.  ``control="positions"`` measures the position half of the state
+        twice the steps (the fine solution becomes the coarse one; so is an estimate that is not finite -- an explicit
+        scheme beyond its stability limit), the accepted solution is the fine one; an estimate far below 1 halves m for
+        the next interval.  ``control="positions"`` measures the position half of the state
         only (velocity components of modes far above 1 / h keep their amplitude but not their phase, which the full
         norm answers with the small steps LSODA itself takes).  Returns (states [n_t, B, 2n], accepted m per interval)."""
         if control not in ("all", "positions"):
@@ -538,35 +583,44 @@ class BeamEnsemble:
 
         def estimate(fine, coarse, start):
             scale = atol + rtol * torch.maximum(fine[:, rows].abs(), start[:, rows].abs())
-            e = ((fine[:, rows] - coarse[:, rows]) / (3.0 * scale)).double()
+            e = ((fine[:, rows] - coarse[:, rows]) / (float(2 ** order - 1) * scale)).double()
             return float(torch.sqrt((e * e).sum(dim=(1, 2, 3)) / n_dof).max().item())
 
-        def run(start, t_start, m):
+        def run(start, t_a, length, on, m):
             self.state = start.clone()
-            self.step_implicit(m, dt_eval / m, t0=t_start, **kw)
+            advance(m, length / m, t_a, on)
             return self.state
 
-        m = max(1, int(np.ceil(dt_eval / 1e-4)))
+        rate = float(m_first) / dt_eval       # steps per second of the coarse solution; doubled / halved by the controller
+        shrink = 0.8 / float(2 ** order)      # half the steps multiply the estimate by 2^order: still below 1 with margin
         out, used = [first], []
         for k in range(n_t - 1):
-            t_k = t0 + k * dt_eval
-            start = self.state
-            coarse = run(start, t_k, m)
-            while True:
-                fine = run(start, t_k, 2 * m)
-                err = estimate(fine, coarse, start)
-                if err <= 1.0:
-                    break
-                m, coarse = 2 * m, fine
-                if 2 * m > max_substeps:
-                    raise RuntimeError(f"solve_ivp: the tolerances ask for more than {max_substeps} steps per t_eval interval "
-                                       f"at t = {t_k:.6g} s (error estimate {err:.3g})")
-            used.append(2 * m)
-            self.state = fine
-            self.time = t0 + (k + 1) * dt_eval
+            t_k, t_n = t0 + k * dt_eval, t0 + (k + 1) * dt_eval
+            pieces = [(t_k, t_n)]
+            if t_switch is not None and t_k + 1e-9 * dt_eval < t_switch < t_n - 1e-9 * dt_eval:
+                pieces = [(t_k, t_switch), (t_switch, t_n)]
+            taken = 0
+            for t_a, t_b in pieces:
+                on = None if t_switch is None else (0.5 * (t_a + t_b) < t_switch)
+                m = max(1, int(np.ceil(rate * (t_b - t_a) - 1e-9)))
+                start = self.state
+                coarse = run(start, t_a, t_b - t_a, on, m)
+                while True:
+                    fine = run(start, t_a, t_b - t_a, on, 2 * m)
+                    err = estimate(fine, coarse, start)
+                    if err <= 1.0:
+                        break
+                    m, coarse, rate = 2 * m, fine, 2.0 * rate
+                    if 2 * m > max_substeps:
+                        raise RuntimeError(f"solve_ivp: the tolerances ask for more than {max_substeps} steps per t_eval "
+                                           f"interval at t = {t_a:.6g} s (error estimate {err:.3g})")
+                taken += 2 * m
+                self.state = fine
+                if err < shrink * 0.25 and m > 1:
+                    rate *= 0.5
+            used.append(taken)
+            self.time = t_n
             out.append(self.unpack_state().unsqueeze(0))
-            if err < 0.05 and m > 1:      # second order: half the steps would still pass (4 x the estimate < 1 with margin)
-                m //= 2
         return torch.cat(out, dim=0), used
 
     def solve_rk45(self, t_end: float, rtol: float = 1e-3, atol: float = 1e-6, impulse_amp=None,

@@ -1572,6 +1572,48 @@ def test_solve_ivp_controls_the_step_by_the_tolerances(golden, name):
         ens.solve_ivp((0.0, 0.002), t_eval[:3], method="LSODA", rtol=1e-15, atol=1e-18, impulse_amp=np.full(2, amp))
 
 
+@pytest.mark.parametrize("name,T", [("lqr6", 0.03), ("lqr24", 0.012)])
+def test_solve_ivp_closed_loop_follows_the_tolerances(golden, name, T):
+    """``solve_ivp(..., gain=K)``: the closed loop of examples/lqr_control.py:94-125 (u = K (0 - x) + impulse inside the RHS,
+    ``solve_ivp(method="LSODA", rtol=1e-8, atol=1e-10)``) for an ensemble -- RK4 with the feedback in every stage, its step
+    chosen by the same step-doubling controller, the input's switch-off a breakpoint of the integration.  Checked against
+    scipy's LSODA at the example's tolerances over the ORACLE's closed-loop RHS (gain of golden G6, 6 and 24 elements):
+    the whole trajectory agrees to 0.1 of the default tolerance band and to within the global error of the tight LSODA run
+    itself (measured: 250 of ITS tolerance units in the velocities, 0.05 in the positions)."""
+    from scipy.integrate import solve_ivp
+
+    z = golden["g6_lqr_loop"]
+    cols, kw = beam_columns(z, name), force_kwargs(z, name)
+    K, amp = z[f"{name}/gain"], float(z[f"{name}/amp"])
+    ob = oracle_beam(cols, **kw)
+    n = ob.n
+
+    def closed_loop(t, x):
+        u = -K @ x
+        if t < 0.01:
+            u[n - 2] += amp
+        return ob.rhs(x, u)
+
+    t_eval = np.arange(0.0, T + 0.0005, 0.001)
+    ref = solve_ivp(closed_loop, (0.0, t_eval[-1]), np.zeros(2 * n), method="LSODA", t_eval=t_eval, rtol=1e-8, atol=1e-10)
+    assert ref.success
+    B = 3
+    ens = ensemble(cols, B, kw)
+    sol = ens.solve_ivp((0.0, t_eval[-1]), t_eval, method="LSODA", rtol=1e-8, atol=1e-10, impulse_amp=np.full(B, amp), gain=K)
+    y = sol.y.cpu().numpy()
+    assert y.shape == (B, 2 * n, t_eval.size) and np.array_equal(y[0], y[B - 1]) and len(sol.substeps) == t_eval.size - 1
+    assert np.max(np.abs(y[0] - ref.y) / (1e-6 + 1e-3 * np.abs(ref.y))) < 0.1
+    tight = np.abs(y[0] - ref.y) / (1e-10 + 1e-8 * np.abs(ref.y))
+    assert tight[:n].max() < 1.0 and tight[n:].max() < 1e3, (tight[:n].max(), tight[n:].max())
+    # integer substeps: no control, the plain stage-split rollout interval by interval
+    e2, e3 = ensemble(cols, B, kw), ensemble(cols, B, kw)
+    s2 = e2.solve_ivp((0.0, 0.003), t_eval[:4], method="RK4", substeps=200, impulse_amp=np.full(B, amp), gain=K)
+    e3.step_feedback(600, 0.001 / 200, K, impulse_amp=np.full(B, amp))
+    assert np.allclose(s2.y[:, :, -1].cpu().numpy(), e3.unpack_state().cpu().numpy(), rtol=1e-12, atol=1e-15)
+    with pytest.raises(ValueError, match="closed loop"):
+        e2.solve_ivp((0.0, 0.003), t_eval[:4], method="RK45", gain=K)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CRB_FUZZ_MIXED_N", "12"))))   # CRB_FUZZ_MIXED_N=200 for a long hunt
 def test_randomised_mixed_ensembles_against_oracle(seed):
     """Differential test over random HETEROGENEOUS ensembles (f-3): every beam draws its own element count, element
