@@ -438,6 +438,25 @@ def worker(args):
     full = [ms for (ms, (_, _, k)) in zip(kernel_ms, events) if k == per_launch] or kernel_ms
     avg_launch_s = float(np.mean(full)) * 1e-3
 
+    # ---- the exchange alone (after the clock stopped; N > 1): how much of the timed region one blocking all-gather of this
+    # rank's terminal states costs by itself -- beams never interact, so this is the only thing a multi-GPU run adds, and
+    # at a few dozen steps it is as long as the stepping (median of 5, max over ranks)
+    exchange_ms = None
+    if dist:
+        red_all = torch.cat([e.unpack_state() for e in enss], dim=0) if n_chunks > 1 else ens.unpack_state()
+        ex = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_ex = time.perf_counter()
+            gather_terminal_states(red_all, sizes=sizes)
+            torch.cuda.synchronize()
+            ex.append(time.perf_counter() - t_ex)
+        tex = torch.tensor([float(np.median(ex))], dtype=torch.float64, device=ens.device)
+        dist.all_reduce(tex, op=dist.ReduceOp.MAX)
+        exchange_ms = float(tex.item()) * 1e3
+        del red_all
+
     # ---- sanity / parity of what was just timed (after the clock stopped)
     state = torch.cat([e.unpack_state() for e in enss], dim=0) if n_chunks > 1 else ens.unpack_state()
     finite = bool(torch.isfinite(state).all())
@@ -560,6 +579,7 @@ def worker(args):
                                       (f" in {n_chunks} chunks, chunk c overlapped with the stepping of chunk c+1" if n_chunks > 1 else ""))
                                      if dist else "none",
                        "gather_chunks": n_chunks,
+                       **({"exchange_alone_ms": exchange_ms} if exchange_ms is not None else {}),
                        "plan_ms": plan_ms,
                        **({"rehearsal": "all ranks on GPU 0, exchange over gloo: NOT a measurement"} if rehearsal else {})},
             "roofline": roofline,
