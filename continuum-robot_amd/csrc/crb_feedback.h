@@ -52,6 +52,9 @@ struct FeedbackParams {
 #ifndef CRB_GEMM_SCHED
 #define CRB_GEMM_SCHED 0
 #endif
+#ifndef CRB_GEMM_WS_SCHED   // wave-specialised kernel: fragment reads of the next pair of sub-steps ahead of the current MFMAs
+#define CRB_GEMM_WS_SCHED 0  // (experiment switch, 1 / 2 / 3 = three interleavings: all measured SLOWER, 227 against 201 us per config-5 step)
+#endif
 template <typename T, int BM, int BN, int BK, int WR, bool HAS_REF>
 __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<T> p) {
     typedef typename MfmaOps<T>::acc_t crb_d4;
@@ -313,6 +316,44 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
 #pragma unroll
             for (int b = 0; b < TN; ++b) acc[b] = MfmaOps<T>::run(af[cur], bf[cur][b], acc[b]);
         }
+#if CRB_GEMM_WS_SCHED
+        // The fragment reads of two sub-steps come out as one ds_read2_b64 per operand (1 + TN reads for 2 TN MFMAs).  Left to
+        // itself the scheduler emits reads -> wait -> MFMAs per pair, so every pair starts with the LDS latency exposed (75
+        // instead of 64 cycles per MFMA, in-kernel stamps).  Asking for the reads of pair g + 1 IN FRONT of the MFMAs of pair g
+        // gives exactly that instruction stream -- and a kernel that is 6.5 us slower (33 % more time per K step), whichever
+        // of the three interleavings below and with the barrier pinned behind the last MFMA: with one matrix wave and one
+        // loader wave per SIMD the bubbles are presumably where the loader wave gets its stores issued.
+#if CRB_GEMM_WS_SCHED == 1
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+        }
+#elif CRB_GEMM_WS_SCHED == 2   // one read behind each of the first MFMAs of a pair
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+#pragma unroll
+            for (int i = 0; i < 1 + TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN - (1 + TN), 0);
+        }
+#elif CRB_GEMM_WS_SCHED == 3   // the reads of the next pair behind the first half of the current pair's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+        }
+#endif
+        // (the barrier stays BEHIND the last MFMA: once the reads run ahead it would otherwise move up to the last read, and
+        //  the matrix waves would wait for the loaders with two pairs of MFMAs still to issue -- measured 229 against 200 us)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         __syncthreads();
     }
     // epilogue: D row (beam) = (lane>>4) + 4*reg, D col (output) = lane&15; scatter into the force layout

@@ -5,7 +5,10 @@ The reference designs a full-state LQR for the linear rod and integrates ONE dis
 10 N for 0.01 s at the tip).  Here the same controller is applied to B copies of the rod, each hit by its own impulse
 amplitude, with the feedback evaluated in every Runge-Kutta stage on the GPU (`BeamEnsemble.step_feedback`).
 
-    python examples/lqr_ensemble.py [--elements 6] [--beams 64] [--t-final 0.05]
+    python examples/lqr_ensemble.py [--elements 6] [--beams 64] [--t-final 0.05] [--lsoda]
+
+--lsoda adds the reference's own call, `solve_ivp(system_with_inputs, method="LSODA", rtol=1e-8, atol=1e-10, t_eval=...)`
+(lqr_control.py:113-125), for the whole ensemble: `BeamEnsemble.solve_ivp(..., gain=K)` chooses the step by these tolerances.
 """
 import argparse
 import time
@@ -26,6 +29,7 @@ def main(argv=None):
     ap.add_argument("--beams", type=int, default=64)
     ap.add_argument("--t-final", type=float, default=0.05)
     ap.add_argument("--dt", type=float, default=5e-6, help="explicit step (the closed loop is stiffer than the rod)")
+    ap.add_argument("--lsoda", action="store_true", help="also integrate the closed loop under tolerance control")
     args = ap.parse_args(argv)
 
     ens = BeamEnsemble(rod(args.elements, "linear"), args.beams, force_params=ForceParams(enable_gravity_effects=True))
@@ -46,9 +50,15 @@ def main(argv=None):
         ens.step_feedback(steps, args.dt, g, impulse_amp=amps)
         tip = ens.tip_displacement().cpu().numpy()
         rows.append((label, tip, time.perf_counter() - t0))
+    if args.lsoda:
+        ens.zero_state()
+        t0 = time.perf_counter()
+        t_eval = np.arange(0.0, args.t_final + 0.5e-3, 1e-3)            # DT of lqr_control.py:31
+        sol = ens.solve_ivp((0.0, float(t_eval[-1])), t_eval, method="LSODA", rtol=1e-8, atol=1e-10, impulse_amp=amps, gain=gain_dev)
+        rows.append((f"LQR, controlled ({max(sol.substeps)} steps/ms)", sol.y[:, n - 2, -1].cpu().numpy(), time.perf_counter() - t0))
     print(f"{args.beams} rods x {args.elements} elements, {steps} RK4 steps of {args.dt:g} s, impulses {amps[0]:.1f} .. {amps[-1]:.1f} N")
     for label, tip, wall in rows:
-        print(f"{label:<10} tip w at t = {args.t_final:g} s: {tip.min():+.4e} .. {tip.max():+.4e} m   ({wall * 1e3:.1f} ms)")
+        print(f"{label:<32} tip w at t = {args.t_final:g} s: {tip.min():+.4e} .. {tip.max():+.4e} m   ({wall * 1e3:.1f} ms)")
     return rows
 
 

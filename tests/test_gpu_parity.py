@@ -1701,6 +1701,8 @@ def test_example_scripts_run_and_agree_with_the_oracle():
     (_, open_tip, _), (_, lqr_tip, _) = rows
     assert np.isfinite(open_tip).all() and np.isfinite(lqr_tip).all()
     assert np.abs(lqr_tip).max() < np.abs(open_tip).max()
+    rows = mods["lqr_ensemble"].main(["--elements", "4", "--beams", "8", "--t-final", "0.01", "--lsoda"])
+    assert len(rows) == 3 and np.allclose(rows[2][1], rows[1][1], rtol=1e-3, atol=1e-9), np.abs(rows[2][1] - rows[1][1]).max()   # the tolerance-controlled run (the fixed-step run sees the end of the impulse in one stage of one step)
 
 
 @pytest.mark.parametrize("n_e,B,kind,kw,bcs", [
