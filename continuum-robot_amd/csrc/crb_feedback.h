@@ -215,6 +215,12 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 // One barrier per K step, taken by both roles.  In-kernel cycle stamps at 2048 x 768 x 384 (64 x 48 tiles,
 // BK 64, 12 K steps): prologue 7.3k cycles (offset table, first tile), per step 3.6k cycles for 48 MFMAs
 // (75 each, 64 = pipe-bound) + 0.4-0.7k at the barrier; 32.7 us against 34.1 us for crb_feedback_kernel.
+#ifndef CRB_WS_PRIO_M   // wave priorities of the two roles
+#define CRB_WS_PRIO_M 2
+#endif
+#ifndef CRB_WS_PRIO_L
+#define CRB_WS_PRIO_L 0
+#endif
 template <typename T, int BN, int BK, bool HAS_REF>
 __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackParams<T> p) {
     typedef typename MfmaOps<T>::acc_t crb_d4;
@@ -233,7 +239,7 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
 
     if (wave >= 4) {
         // ------------------------------------------------ loader role
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(CRB_WS_PRIO_L);
         const int lt = t - 256;
         const int lk = lt & (BK - 1), lr = lt / BK;
         const T* xrow[QA];
@@ -292,7 +298,7 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
         return;
     }
     // ---------------------------------------------------- matrix role
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(CRB_WS_PRIO_M);
     crb_d4 acc[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[b] = crb_d4{T(0), T(0), T(0), T(0)};
