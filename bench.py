@@ -595,6 +595,9 @@ def worker(args):
                 if key in tj:
                     out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = tj[key].get("source")
+                    if "stage_kernel" in out["roofline"] and "stage_kernel_hbm_bytes_per_launch" in tj[key]:
+                        out["roofline"]["stage_kernel"]["traffic"] = tj[key]["stage_kernel_hbm_bytes_per_launch"]
+                        out["roofline"]["stage_kernel"]["traffic_source"] = tj[key].get("stage_kernel_source")
                     if "valu_instr_per_elem_step" in tj[key] and gain is None:
                         # the limiter that actually binds: vector-ALU issue slots (one wave instruction per
                         # SIMD every 4 cycles, 1024 SIMDs, nominal 2.4 GHz), instruction count from the PMC run
