@@ -1,7 +1,7 @@
 """measurement helper: the tolerance-controlled closed loop (BeamEnsemble.solve_ivp(..., gain=K)) against scipy LSODA at the
 tolerances of examples/lqr_control.py:117-125 over the ORACLE's closed-loop RHS (CPU), 6- and 24-element beams of golden G6."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it uses the oracle as its checker)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "continuum-robot_amd")]
 import numpy as np, torch
 from scipy.integrate import solve_ivp

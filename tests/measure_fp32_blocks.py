@@ -1,7 +1,7 @@
 """Measure the per-DOF-block drift of the fp32 plan against the fp64 oracle over the whole config-4 ensemble
 (sets FP32_TOL of tests/test_gpu_parity.py)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it uses the oracle as its checker)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "continuum-robot_amd")]
 import numpy as np, torch
 from continuum_robot.batched import BeamEnsemble

@@ -326,7 +326,7 @@ def test_fp32_plan_tracks_fp64_within_measured_drift():
 
 
 # fp32 plans vs the fp64 oracle, nonlinear + drag, 200 steps, per DOF block: the bound asserted = ~3x the worst
-# over the whole 4096 x 256 ensemble measured on MI355X (profiles/exp_fp32_blocks.py: u 1.9e-6, w 8.4e-7, phi 1.0e-6,
+# over the whole 4096 x 256 ensemble measured on MI355X (tests/measure_fp32_blocks.py: u 1.9e-6, w 8.4e-7, phi 1.0e-6,
 # du/dt 3.5e-5, dw/dt 1.7e-6, dphi/dt 9.2e-6).  The transverse blocks -- what the examples read -- keep 6 digits;
 # the axial rate is a second-order quantity (|du/dt| ~ 1e-7 against |dw/dt| ~ 1e-2) driven by a difference of O(1)
 # terms and keeps 4.
