@@ -215,6 +215,9 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 // One barrier per K step, taken by both roles.  In-kernel cycle stamps at 2048 x 768 x 384 (64 x 48 tiles,
 // BK 64, 12 K steps): prologue 7.3k cycles (offset table, first tile), per step 3.6k cycles for 48 MFMAs
 // (75 each, 64 = pipe-bound) + 0.4-0.7k at the barrier; 32.7 us against 34.1 us for crb_feedback_kernel.
+#ifndef CRB_WS_PROBE    // timing probes of the wave-specialised kernel (results are WRONG): 1 = loaders only, 2 = matrix waves only
+#define CRB_WS_PROBE 0
+#endif
 #ifndef CRB_WS_PRIO_M   // wave priorities of the two roles
 #define CRB_WS_PRIO_M 2
 #endif
@@ -281,6 +284,11 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
 #pragma unroll
             for (int q = 0; q < QB; ++q) Bt[(lr + RSTEP * q) * LD + lk] = R.gb[q] * R.kmask;
         };
+#if CRB_WS_PROBE == 2   // (timing probe: loaders idle, the matrix waves run over whatever LDS holds)
+        __syncthreads();
+        for (int sidx = 0; sidx < nsteps; ++sidx) __syncthreads();
+        return;
+#endif
         fetch(R0, 0);
         fetch(R1, BK);
         stash(R0, 0);
@@ -304,6 +312,10 @@ __global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackPara
     for (int b = 0; b < TN; ++b) acc[b] = crb_d4{T(0), T(0), T(0), T(0)};
     __syncthreads();                           // stage 0 ready
     for (int sidx = 0; sidx < nsteps; ++sidx) {
+#if CRB_WS_PROBE == 1   // (timing probe: matrix waves idle, the loaders alone set the pace)
+        __syncthreads();
+        continue;
+#endif
         const int st = sidx & 1;
         const T* Aw = As + st * BM * LD + (16 * wave + (lane & 15)) * LD + (lane >> 4);
         const T* Bw = Bs + st * BN * LD + (lane & 15) * LD + (lane >> 4);
