@@ -215,6 +215,10 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 // One barrier per K step, taken by both roles.  In-kernel cycle stamps at 2048 x 768 x 384 (64 x 48 tiles,
 // BK 64, 12 K steps): prologue 7.3k cycles (offset table, first tile), per step 3.6k cycles for 48 MFMAs
 // (75 each, 64 = pipe-bound) + 0.4-0.7k at the barrier; 32.7 us against 34.1 us for crb_feedback_kernel.
+#ifndef CRB_WS_NL       // loader threads of the wave-specialised kernel: 512 = two loader waves per SIMD behind the one matrix wave
+                        // (256 = one: config 5 200.9 -> 196.5 us per step with two)
+#define CRB_WS_NL 512
+#endif
 #ifndef CRB_WS_PROBE    // timing probes of the wave-specialised kernel (results are WRONG): 1 = loaders only, 2 = matrix waves only
 #define CRB_WS_PROBE 0
 #endif
@@ -225,18 +229,18 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 #define CRB_WS_PRIO_L 0
 #endif
 template <typename T, int BN, int BK, bool HAS_REF>
-__global__ void __launch_bounds__(512) crb_feedback_ws_kernel(const FeedbackParams<T> p) {
+__global__ void __launch_bounds__(256 + CRB_WS_NL) crb_feedback_ws_kernel(const FeedbackParams<T> p) {
     typedef typename MfmaOps<T>::acc_t crb_d4;
-    constexpr int BM = 64, TN = BN / 16, LD = BK + 2;
-    constexpr int QA = BM * BK / 256, QB = BN * BK / 256, RSTEP = 256 / BK;
-    static_assert(BN % 16 == 0 && 256 % BK == 0 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile shape");
+    constexpr int BM = 64, TN = BN / 16, LD = BK + 2, NL = CRB_WS_NL;   // NL loader threads behind the 256 matrix threads
+    constexpr int QA = BM * BK / NL, QB = BN * BK / NL, RSTEP = NL / BK;
+    static_assert(BN % 16 == 0 && NL % BK == 0 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const As = reinterpret_cast<T*>(crb_smem);          // [2][BM * LD]
     T* const Bs = As + 2 * BM * LD;                             // [2][BN * LD]
     int32_t* const coff_s = reinterpret_cast<int32_t*>(Bs + 2 * BN * LD);  // [n2]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    for (int k = t; k < p.n2; k += 512) coff_s[k] = p.col_off[k];
+    for (int k = t; k < p.n2; k += 256 + NL) coff_s[k] = p.col_off[k];
     const int nsteps = (p.n2 + BK - 1) / BK;
     __syncthreads();  // coff_s
 
