@@ -1203,7 +1203,8 @@ int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
         p->stiff_alpha = alpha;
         return CRB_OK;
     }
-    set->alpha = 0.0;   // (not valid until the build below has been queued)
+    set->alpha = 0.0;   // (not valid until the build below has been queued; neither is "the set in use" if a launch below fails)
+    p->stiff_alpha = 0.0;
     AsmParams a = in.a;
     a.alpha = alpha;
     a.slot_out = nullptr; a.lv64 = nullptr; a.fin64_all = nullptr; a.blocks0 = nullptr;
