@@ -716,8 +716,20 @@ class BeamEnsemble:
                                                       self._ptr(K), self._ptr(ref), C.byref(desc), self._ptr(work),
                                                       C.byref(t_end), self._stream()))
         self._keep = keep + [K, ref, work]
+        self._feedback_work = work
         self.time = float(t_end.value)
         return self.time
+
+    def feedback_status(self) -> int:
+        """0, or which hand-off of the last `step_feedback` gave up (the persistent stepper's workgroups wait for each
+        other with a time limit instead of hanging the device; the state is unusable then).  Synchronises the stream."""
+        work = getattr(self, "_feedback_work", None)
+        if work is None:
+            return 0
+        status = C.c_int32(0)
+        with self._on_device():
+            nat.check(self._lib.crb_feedback_status(self.plan.h, self._ptr(work), C.byref(status), self._stream()))
+        return int(status.value)
 
     # ------------------------------------------------------------------ functional composition
     def _plan_with(self, drag_on: bool, gravity_on: bool):

@@ -1,0 +1,588 @@
+// crb_loop.h -- the closed-loop (LQR) RK4 rollout of an ensemble as ONE persistent launch.
+//
+// examples/lqr_control.py:95-125 integrates  x' = f(t, x, K (r - x))  (control/full_state_linear.py:81): the
+// controller is part of the right-hand side, so a classical RK4 step needs the product U = (R - X) K^T -- a
+// [B x 2n] . [2n x n] GEMM -- at each of its four stages, between two halves that want opposite decompositions:
+//   * the GEMM wants the gain split by OUTPUT COLUMNS so that a workgroup's slice of K never moves again,
+//   * the mass solve (cyclic reduction along the beam) wants WHOLE BEAMS in one workgroup.
+// The stage-split path (crb_feedback_ws_kernel + crb_stage_lean_kernel, 8 launches per step) pays for that
+// transposition with ~38 node records per node-step through HBM and re-streams the gain through LDS in every
+// launch.  Here a GROUP of NB workgroups owns a row block of 64 beams for the whole rollout:
+//   GEMM phase   workgroup y of the group computes U[64 beams][48 columns = nodes 16y .. 16y+15] on
+//                v_mfma_f64_16x16x4_f64.  Its gain slice [48 x 2n] is loaded into REGISTERS once per launch (four
+//                waves, K split four ways: 18 NB fragments of one double per lane and wave = 288 VGPRs at NB = 8);
+//                only the stage states (the A operand) stream, straight from L2 into MFMA fragments: the buffer that
+//                holds them is laid out fragment-major, so every load is a contiguous 1.5 KB per wave and needs no
+//                LDS staging, no loader waves and no offset tables.
+//   hand-off     split-K partials are summed through LDS, the tile is published (write-through stores, one counter
+//                add per workgroup), the group waits for its NB tiles.
+//   stage phase  workgroup y takes beams 64/NB * y ... of the row block: element forces, gravity, drag, the mass solve
+//                (the lean exchange structure of crb_lean.h) and the RK4 bookkeeping.  The RK4 accumulator and the solve
+//                tables stay in LDS (the register file belongs to the gain), the step's start state in a buffer of the
+//                workgroup's own that no other workgroup touches (L2); the new stage state goes back to the fragment
+//                buffer; hand-off.
+// HBM sees the state once at the start and once at the end of the rollout.  Workgroups of different groups never
+// wait for each other.
+//
+// Hand-off protocol (MI355X_MICROARCH.md, 'inter-workgroup visibility', first row of the table of valid forms): every
+// byte that changes hands is stored write-through (sc1) and loaded with sc1 (never from this CU's L1); every storing
+// wave drains its stores (s_waitcnt vmcnt(0)), the workgroup's barrier follows, ONE lane adds to the group's
+// monotonic counter (agent scope) and polls it (relaxed, s_sleep) until all NB workgroups of the group have arrived;
+// the other waves load behind the barrier that lane then joins.  Results do not depend on dispatch order or
+// workgroup -> XCD placement: roles are handed out by a ticket counter in START order, so the members of every
+// group but the last one started are running, and a wait gives up after `timeout` ticks of the 100 MHz clock
+// (error word set, every workgroup leaves) instead of hanging the device.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "crb_feedback.h"
+#include "crb_lean.h"
+
+namespace crb {
+
+constexpr int LOOP_SYNC_WORDS = 2048;   // 8 KB at the start of the work buffer: [0] ticket, [1] error, counters at [32 + 32 g]
+constexpr int LOOP_MAX_GROUPS = (LOOP_SYNC_WORDS - 32) / 32;
+constexpr int LOOP_SC1 = 16;            // aux bit of the raw buffer intrinsics: sc1 (write-through store / L1-bypassing load)
+#ifndef CRB_LOOP_DEPTH                  // slot pairs of A fragments in flight ahead of the MFMAs (24 VGPRs each)
+#define CRB_LOOP_DEPTH 4
+#endif
+
+template <typename T>
+struct LoopParams {
+    KParams<T> k;              // tables, state, impulse, clock (as for the stage kernel)
+    const T* kfrag;            // [NB][4 waves][3][6 NB][64 lanes]: the gain as the workgroups' MFMA B fragments (crb_loop_gain_kernel)
+    const T* ref;              // [B][2n] reduced, or nullptr (= regulation to 0)
+    const int32_t* red_map;    // [3 n_node]: reduced index of a full DOF or -1 (reference vectors, HAS_REF)
+    int n_red;                 // n
+    T* ebuf;                   // [groups][SP][64][12]  stage state (HAS_REF: r - state) in fragment order
+    T* xnbuf;                  // HAS_REF only: the stage state itself, same order
+    T* ubuf;                   // [groups][64][48 NB]   feedback force per beam and padded slot DOF
+    T* x0buf;                  // [groups][64][16 NB][6] the step's start state, private to the workgroup that owns the beam
+    unsigned* sync;            // LOOP_SYNC_WORDS words, zeroed before the launch
+    int n_rb, n_groups;        // row blocks of 64 beams; groups of NB workgroups in the grid
+    int fences;                // 1: agent-scope release / acquire fences around every hand-off as well (debugging aid)
+    unsigned long long timeout;
+};
+
+template <int NB>
+__host__ __device__ constexpr size_t loop_ebuf_elems() { return size_t(8 * NB) * 64 * 12; }
+template <int NB>
+__host__ __device__ constexpr size_t loop_ubuf_elems() { return size_t(64) * 48 * NB; }
+// per-slot table record in LDS, in 16-byte items: [LV levels x 10 multipliers][final 5, drag][element c0..c5][half masses own, left]
+template <int LV>
+__host__ __device__ constexpr int loop_tab_items() { return (LV * 10 + 14) / 2; }
+template <typename T, int LV, int LOGNW, int NB>
+__host__ __device__ constexpr size_t loop_lds_bytes() {
+    constexpr int NTB = 64 << LOGNW, BPW = 64 / NB, BPP = 256 / NTB;
+    // RK4 accumulator of the workgroup's beams + solve tables + element kinds + max(split-K scratch of six 16 x 48 partial
+    // tiles, exchange columns) + 16 B
+    const size_t acc = size_t(6) * BPW * NTB * sizeof(T);
+    const size_t tab = size_t(loop_tab_items<LV>()) * NTB * 2 * sizeof(T) + size_t(NTB) * sizeof(int32_t);
+    const size_t red = size_t(6) * 3 * 4 * 64 * sizeof(T);
+    const size_t xch = size_t(BPP) * (9 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)) * (NTB + 1) * sizeof(T);
+    return acc + tab + ((red > xch ? red : xch) + 15) / 16 * 16 + 16;
+}
+
+typedef unsigned loop_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned loop_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double loop_d(unsigned lo, unsigned hi) { return __hiloint2double(int(hi), int(lo)); }
+__device__ __forceinline__ loop_u4 loop_pack(double a, double b) {
+    return loop_u4{unsigned(__double2loint(a)), unsigned(__double2hiint(a)), unsigned(__double2loint(b)), unsigned(__double2hiint(b))};
+}
+// three / six consecutive doubles at byte offset `off` of a buffer, L1-bypassing
+__device__ __forceinline__ void loop_ld3(__amdgpu_buffer_rsrc_t r, unsigned off, double o[3]) {
+    const loop_u4 a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LOOP_SC1);
+    const loop_u2 b = __builtin_amdgcn_raw_buffer_load_b64(r, off + 16, 0, LOOP_SC1);
+    o[0] = loop_d(a[0], a[1]); o[1] = loop_d(a[2], a[3]); o[2] = loop_d(b[0], b[1]);
+}
+__device__ __forceinline__ void loop_ld6(__amdgpu_buffer_rsrc_t r, unsigned off, double q[3], double v[3]) {
+    const loop_u4 a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, LOOP_SC1);
+    const loop_u4 b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, LOOP_SC1);
+    const loop_u4 c = __builtin_amdgcn_raw_buffer_load_b128(r, off + 32, 0, LOOP_SC1);
+    q[0] = loop_d(a[0], a[1]); q[1] = loop_d(a[2], a[3]); q[2] = loop_d(b[0], b[1]);
+    v[0] = loop_d(b[2], b[3]); v[1] = loop_d(c[0], c[1]); v[2] = loop_d(c[2], c[3]);
+}
+__device__ __forceinline__ void loop_st6(__amdgpu_buffer_rsrc_t r, unsigned off, const double q[3], const double v[3]) {
+    __builtin_amdgcn_raw_buffer_store_b128(loop_pack(q[0], q[1]), r, off, 0, LOOP_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(loop_pack(q[2], v[0]), r, off + 16, 0, LOOP_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(loop_pack(v[1], v[2]), r, off + 32, 0, LOOP_SC1);
+}
+
+// The gain slice of a workgroup is 18 NB doubles per lane: 288 registers at NB = 8, more than the 256 accumulator
+// registers.  The matrix instruction is written out so that the register CLASS of every fragment is fixed -- all but the
+// last 3 * 6 NB - 128 in accumulator registers (which vector-ALU code cannot touch, so the stage phase cannot evict
+// them), the rest and the sums in vector registers.  Left to the compiler the sums take the accumulator file, a third of
+// the slice spills to scratch and the A loads sink to their first use.
+template <int NB>
+__host__ __device__ constexpr bool loop_b_in_vgpr(int n, int ks) { return n * 6 * NB + ks >= 128; }
+__device__ __forceinline__ void loop_mfma(bool B_IN_VGPR /* a constant once the loops are unrolled */, typename MfmaOps<double>::acc_t& c, double a, double b) {
+    // (s_nop 1: a freshly copied operand may not feed the matrix pipe at once; the sum chains on itself without a wait)
+    if (B_IN_VGPR) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+}
+
+// The gain [n][2n] (reduced ordering, linear_quadratic_regulator.py:84-191) re-laid as the MFMA B fragments of the
+// persistent kernel's workgroups: out[y][wave][n][ks][lane] = K[row][col] with
+//   row = DOF (48 y + 16 n + (lane & 15)) of the padded slot-major order (slot = row / 3, dof = row % 3),
+//   col = (slot 2 (2 NB wave + ks / 3) + (lane >> 5), plane (lane >> 4) & 1, dof ks % 3),
+// zero where either DOF is constrained or lies in the padding.  One thread per value.
+template <typename T, int NB>
+__global__ void crb_loop_gain_kernel(const T* gain, const int32_t* red_map, int n_red, int S, int off, T* out) {
+    constexpr int SPW = 2 * NB, KSW = 3 * SPW;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NB * 4 * 3 * KSW * 64) return;
+    const int lane = idx & 63, ks = (idx >> 6) % KSW, n = (idx >> 6) / KSW % 3, wave = (idx >> 6) / (3 * KSW) % 4, y = (idx >> 6) / (12 * KSW);
+    const int fi = lane & 15, kq = lane >> 4;
+    const int r = 48 * y + 16 * n + fi, slot_r = r / 3, dof_r = r - 3 * slot_r;
+    const int spl = ks / 3, tt = ks - 3 * spl;
+    const int slot_c = 2 * (SPW * wave + spl) + (kq >> 1);
+    const int redr = slot_r < S ? red_map[3 * (slot_r + off) + dof_r] : -1;
+    const int redc = slot_c < S ? red_map[3 * (slot_c + off) + tt] : -1;
+    out[idx] = (redr >= 0 && redc >= 0) ? gain[size_t(redr) * 2 * n_red + size_t(kq & 1) * n_red + redc] : T(0);
+}
+
+// One RHS  a = Minv (uadd - k(q) + drag + gravity)  for NTB = 64 << LOGNW threads that carry one beam: the exchange
+// structure of lean_rhs (crb_lean.h) plus the plain cantilever's nearest-neighbour gravity, as crb_stage_lean_kernel
+// evaluates it -- with every table value read from LDS where it is used (`tab`: this thread's record, 16-byte item k
+// at tab[2 k NTB]) instead of living in registers.  `lds3` is this beam's own exchange region, `tl` the thread's index
+// inside the beam.  Barriers are workgroup-wide: every beam of the workgroup runs through here in lockstep.
+template <typename T, int LV, int LOGNW, bool GRAV, int EM>
+__device__ __forceinline__ void loop_rhs(const T* tab, int kind, T gx, T gy, bool corrected, bool drag_on, T* lds3, int tl, int lane,
+                                         int j, int S, bool valid, const T sq[3], const T sv[3], const T uadd[3], T a[3]) {
+    static_assert(LOGNW <= 1, "levels above 0 are lane shifts");
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    auto item = [&](int k) { return *reinterpret_cast<const t2*>(tab + size_t(2 * k) * NT); };
+    T* const ldsQ = lds3;                           // [3][NT+1]  stage positions
+    T* const ldsA = lds3 + 3 * size_t(NT + 1);      // [6][NT+1]  p0..2, fl0..2
+    auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
+    const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S;
+    const int t_l1 = has_left ? thread_of(j - 1) : NULLT;
+    const int t_r1 = has_right ? thread_of(j + 1) : NULLT;
+    const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
+    T qL[3], phiR = T(0);
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(sq[c], lane);
+        if (GRAV) phiR = lane_higher<T, 1>(sq[2], lane);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ldsQ[size_t(c) * (NT + 1) + tl] = sq[c];
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qL[c] = ldsQ[size_t(c) * (NT + 1) + t_l1];
+        if (GRAV) phiR = ldsQ[size_t(2) * (NT + 1) + t_r1];
+    }
+    ElemCoef<T> ec;
+    {
+        const t2 c01 = item(5 * LV + 3), c23 = item(5 * LV + 4), c45 = item(5 * LV + 5);
+        ec.c[0] = c01[0]; ec.c[1] = c01[1]; ec.c[2] = c23[0]; ec.c[3] = c23[1]; ec.c[4] = c45[0]; ec.c[5] = c45[1];
+        ec.kind = kind;
+    }
+    T fl[3], fr[3];
+    if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
+    else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
+    else elem_force<T>(ec, qL, sq, corrected, fl, fr);
+    T pp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pp[c] = uadd[c] - fr[c];
+    const t2 f4d = item(5 * LV + 2);   // [final 4, drag]
+    pp[1] += drag_force<T>(drag_on ? f4d[1] : T(0), sv[1]);
+    if (GRAV) {   // gravity_forces.py:104-146 on the plain cantilever: segment j averages the rotations of slots j, j+1
+        const t2 hm = item(5 * LV + 6);   // [half mass of segment j, of segment j-1]
+        T g_own[2], g_left[2];
+        gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], gx, gy, hm[0], g_own);
+        if (LOGNW == 0) {
+            g_left[0] = lane_lower<T, 1>(g_own[0], lane);
+            g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+        } else {
+            gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), gx, gy, hm[1], g_left);
+        }
+        pp[0] += g_own[0] + g_left[0];
+        pp[1] += g_own[1] + g_left[1];
+    }
+    T r[3], rlo[3], rhi[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+            rlo[c] = lane_lower<T, 1>(r[c], lane);
+            rhi[c] = lane_higher<T, 1>(r[c], lane);
+        }
+    } else {
+        auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { col(c, tl) = pp[c]; col(3 + c, tl) = fl[c]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rlo[c] = col(c, t_l1) - fl[c];
+            r[c] = pp[c] - col(3 + c, t_r1);
+            rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LV; ++l) {
+        if (l > 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                switch (l - LOGNW) {
+                    case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
+                    case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
+                    case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
+                    case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
+                    case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
+                    default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
+                }
+            }
+        }
+        T cfl[PCR_LEVEL_VALS];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const t2 v = item(5 * l + k); cfl[2 * k] = v[0]; cfl[2 * k + 1] = v[1]; }
+        pcr_apply_level<T>(cfl, rlo, rhi, r);
+    }
+    const t2 f01 = item(5 * LV), f23 = item(5 * LV + 1);
+    const T fin[5] = {f01[0], f01[1], f23[0], f23[1], f4d[0]};
+    pcr_apply_final<T>(fin, r, a);
+}
+
+// NB workgroups per group (= column blocks of 48 = 16 slots each; slots padded to 16 NB = the threads that carry a beam),
+// LOGNW as in the lean kernels (waves per beam).  256 threads, one workgroup per CU (the gain slice wants the
+// whole register file).
+template <typename T, int LV, int LOGNW, int NB, bool GRAV, int EM, bool HAS_REF>
+__global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P) {
+    static_assert(sizeof(T) == 8, "the persistent closed-loop stepper is built for fp64 plans");
+    typedef typename MfmaOps<T>::acc_t acc4;
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    constexpr int SPAD = 16 * NB, NCOL = 3 * SPAD, SPW = 2 * NB, KSW = 3 * SPW, D = CRB_LOOP_DEPTH;
+    constexpr int NTB = 64 << LOGNW, BPP = 256 / NTB, BPW = 64 / NB, NPASS = BPW / BPP, NLI = BPW * NTB;
+    static_assert(SPAD == NTB, "one thread per padded slot");
+    static_assert(NPASS * BPP == BPW && BPW * NB == 64, "beams of a row block divide evenly");
+    static_assert(D >= 2 && D <= SPW, "pipeline depth");
+    constexpr int XCH = (9 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)) * (NTB + 1);   // exchange doubles per beam in flight
+    constexpr int ITEMS = loop_tab_items<LV>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
+    T* const accs = reinterpret_cast<T*>(crb_smem);                 // [6][NLI]: RK4 accumulator q, v
+    T* const tabs = accs + size_t(6) * NLI;                         // [ITEMS][NTB][2]
+    int32_t* const kinds = reinterpret_cast<int32_t*>(tabs + size_t(ITEMS) * NTB * 2);   // [NTB]
+    T* const scratch = reinterpret_cast<T*>(kinds + NTB);
+    unsigned* const sh = reinterpret_cast<unsigned*>(crb_smem + loop_lds_bytes<T, LV, LOGNW, NB>() - 16);
+    const KParams<T>& p = P.k;
+    // (the wave index is made provably uniform: everything derived from it -- roles, LDS bases, branches -- stays scalar)
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+    // ---- role: tickets in start order
+    if (t == 0) sh[0] = __hip_atomic_fetch_add(P.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = sh[0];
+    const int group = __builtin_amdgcn_readfirstlane(int(ticket / NB)), y = __builtin_amdgcn_readfirstlane(int(ticket % NB));
+    if (group >= P.n_groups) return;
+    unsigned* const counter = P.sync + 32 + 32 * group;
+    unsigned* const errw = P.sync + 1;
+    unsigned arrivals = 0;   // hand-offs this group has been through
+    // hand-off: true = every workgroup of the group has arrived; false = give up (timeout or another group's error)
+    auto handoff = [&]() -> bool {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+        __syncthreads();
+        ++arrivals;
+        if (t == 0) {
+            if (P.fences) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = arrivals * NB;
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            unsigned ok = 1;
+            for (unsigned spins = 0;; ++spins) {
+                if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                __builtin_amdgcn_s_sleep(2);
+                if ((spins & 255u) == 255u) {
+                    if (__hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+                    if (__builtin_amdgcn_s_memrealtime() - t_start > P.timeout) {
+                        __hip_atomic_store(errw, 1u + unsigned(group), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            if (P.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            sh[1] = ok;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        return sh[1] != 0u;
+    };
+
+    // ---- GEMM role of this thread: wave = K quarter (slot pairs SPW wave ...), lane = (row / column fi, k quarter kq)
+    const int fi = lane & 15, kq = lane >> 4;
+    // gain slice in registers: Bf[n][3 spl + tt] = K[row 48 y + 16 n + fi][column of (slot 2 sp + (kq >> 1), plane kq & 1, dof tt)],
+    // prepared in exactly this order by crb_loop_gain_kernel: coalesced loads, once per launch
+    T Bf[3][KSW];
+    {
+        const T* src = P.kfrag + (size_t(y) * 4 + wave) * 3 * KSW * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) Bf[n][ks] = src[size_t(n * KSW + ks) * 64];
+    }
+    // ---- stage role: beam `sub` of the pass, slot j
+    const int sub = wave >> LOGNW, wib = wave & ((1 << LOGNW) - 1), tl = (wib << 6) | lane;
+    const int S = p.S;
+    const int j = (lane << LOGNW) | wib;
+    const bool slot_ok = j < S;
+    T* const lds3 = scratch + size_t(sub) * XCH;
+    const T* const tab = tabs + size_t(2) * tl;
+    const bool corrected = (p.flags & 4u) != 0, drag_on = (p.flags & 1u) != 0;
+    const size_t plane = size_t(p.n_node) * 4;
+    const T dt = T(p.dt), hdt = T(0.5 * p.dt), dt6 = T(p.dt / 6.0);
+    // ---- the solve tables of slot j into LDS, once (every beam of a shared-table plan uses the same ones)
+    if (sub == 0) {
+        auto put = [&](int k, T a0, T a1) { *reinterpret_cast<t2*>(tabs + (size_t(k) * NTB + tl) * 2) = t2{a0, a1}; };
+        if (slot_ok) {
+            const SlotConst<T>& sc = p.slot[j];
+#pragma unroll
+            for (int l = 0; l < LV; ++l) {
+                const T* src = p.pcr_levels + (size_t(l) * size_t(S) + size_t(j)) * PCR_LEVEL_VALS;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) put(5 * l + k, src[2 * k], src[2 * k + 1]);
+            }
+            const T* fin = p.pcr_final + size_t(j) * PCR_FINAL_VALS;
+            put(5 * LV, fin[0], fin[1]);
+            put(5 * LV + 1, fin[2], fin[3]);
+            put(5 * LV + 2, fin[4], sc.drag);
+            put(5 * LV + 3, sc.elem.c[0], sc.elem.c[1]);
+            put(5 * LV + 4, sc.elem.c[2], sc.elem.c[3]);
+            put(5 * LV + 5, sc.elem.c[4], sc.elem.c[5]);
+            put(5 * LV + 6, sc.half_mass, j >= 1 ? p.slot[j - 1].half_mass : T(0));
+            kinds[tl] = sc.elem.kind;
+        } else {
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) put(k, T(0), T(0));
+            kinds[tl] = KIND_NONE;
+        }
+    }
+    int red[3] = {-1, -1, -1};
+    if (HAS_REF && slot_ok) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) red[c] = P.red_map[3 * (j + p.off) + c];
+    }
+    const __amdgpu_buffer_rsrc_t ers =
+        __builtin_amdgcn_make_buffer_rsrc(P.ebuf + size_t(group) * loop_ebuf_elems<NB>(), 0, unsigned(loop_ebuf_elems<NB>() * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc((HAS_REF ? P.xnbuf : P.ebuf) + size_t(group) * loop_ebuf_elems<NB>(), 0,
+                                          unsigned(loop_ebuf_elems<NB>() * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs =
+        __builtin_amdgcn_make_buffer_rsrc(P.ubuf + size_t(group) * loop_ubuf_elems<NB>(), 0, unsigned(loop_ubuf_elems<NB>() * sizeof(T)), 0x00020000);
+    // the step's start state of this thread's beams: [pass][256 threads][6], nobody else's business (plain accesses)
+    T* const x0mine = P.x0buf + ((size_t(group) * NB + y) * NLI + t) * 6;
+    // byte offsets: this lane's first A fragment; this thread's stage record / force of beam `bl` of the workgroup
+    const unsigned a_off0 = unsigned((((SPW * wave) * 64 + fi) * 12 + 3 * kq) * sizeof(T));
+    auto e_off = [&](int bl) { return unsigned((((j >> 1) * 64 + (y * BPW + bl)) * 12 + (j & 1) * 6) * sizeof(T)); };
+    auto u_off = [&](int bl) { return unsigned(((y * BPW + bl) * NCOL + 3 * j) * sizeof(T)); };
+    const int kind = 0;   // (set after the tables' barrier below)
+    (void)kind;
+
+    for (int rb = group; rb < P.n_rb; rb += P.n_groups) {
+        // ---- prologue: the workgroup's beams into its private start-state buffer and into the fragment buffer
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int bl = pass * BPP + sub, beam = rb * 64 + y * BPW + bl;
+            T xq[3] = {T(0), T(0), T(0)}, xv[3] = {T(0), T(0), T(0)};
+            if (slot_ok && beam < p.B) {
+                const SlotConst<T>& sc = p.slot[j];
+                const size_t xoff = size_t(beam) * 2 * plane + size_t(j + p.off) * 4;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { xq[c] = p.x[xoff + c] * sc.mask[c]; xv[c] = p.x[xoff + plane + c] * sc.mask[c]; }
+            }
+            t2* x0p = reinterpret_cast<t2*>(x0mine + size_t(pass) * 256 * 6);
+            x0p[0] = t2{xq[0], xq[1]}; x0p[1] = t2{xq[2], xv[0]}; x0p[2] = t2{xv[1], xv[2]};
+            if (HAS_REF) {
+                T eq[3] = {T(0), T(0), T(0)}, ev[3] = {T(0), T(0), T(0)};
+                if (beam < p.B) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (red[c] >= 0) {
+                            eq[c] = P.ref[size_t(beam) * 2 * P.n_red + red[c]] - xq[c];
+                            ev[c] = P.ref[size_t(beam) * 2 * P.n_red + P.n_red + red[c]] - xv[c];
+                        }
+                }
+                loop_st6(ers, e_off(bl), eq, ev);
+                loop_st6(xrs, e_off(bl), xq, xv);
+            } else {
+                loop_st6(ers, e_off(bl), xq, xv);
+            }
+        }
+        if (!handoff()) return;   // (its barriers also publish the tables in LDS)
+        const int my_kind = kinds[tl];
+
+        double tc = p.t0;
+#pragma unroll 1
+        for (int step = 0; step < p.n_steps; ++step) {
+            const double t_half = __dadd_rn(tc, 0.5 * p.dt), t_full = __dadd_rn(tc, p.dt);
+            const bool last_step = step + 1 == p.n_steps;
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                // ======================================================== GEMM phase: U tile = E . Kslice^T
+                acc4 acc[4][3];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) acc[m][n] = acc4{T(0), T(0), T(0), T(0)};
+                {
+                    // ring of D register sets: the loads of slot pairs spl + 1 .. spl + D - 1 fly while spl is multiplied
+                    // (pinned by scheduling barriers: left alone, the scheduler sinks every load to its first use)
+                    T af[D][4][3];
+                    auto fetch = [&](int spl) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) loop_ld3(ers, a_off0 + unsigned((spl * 64 + 16 * m) * 12 * sizeof(T)), af[spl % D][m]);
+                    };
+#pragma unroll
+                    for (int d = 0; d < D - 1; ++d) fetch(d);
+#pragma unroll
+                    for (int spl = 0; spl < SPW; ++spl) {
+                        if (spl + D - 1 < SPW) fetch(spl + D - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                for (int n = 0; n < 3; ++n) loop_mfma(loop_b_in_vgpr<NB>(n, 3 * spl + tt), acc[m][n], af[spl % D][m][tt], Bf[n][3 * spl + tt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // (an MFMA's result is readable by other instructions only some cycles after issue; nothing pads that for asm)
+                    asm volatile("s_nop 15\n\ts_nop 15"
+                                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]),
+                                   "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]));
+                }
+                // ---- split-K: wave w owns row tile m = w; partial tiles change hands through LDS, two owners per round.
+                // (addresses are formed from ONE laundered base per use: hoisted out of the step loop, the 100-odd
+                //  distinct addresses of this block would each take a register and end in scratch)
+                unsigned red_base = unsigned(reinterpret_cast<unsigned char*>(scratch) - crb_smem) + unsigned(lane) * unsigned(sizeof(T));
+                unsigned u_base = unsigned((((lane >> 4) + 16 * wave) * NCOL + 48 * y + fi) * sizeof(T));
+                asm volatile("" : "+v"(red_base), "+v"(u_base));
+#pragma unroll
+                for (int round = 0; round < 2; ++round) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        const int m = 2 * round + mm;
+                        if (wave != m) {
+                            const int rank = wave < m ? wave : wave - 1;
+                            unsigned char* dst = crb_smem + red_base + unsigned((mm * 3 + rank) * 12 * 64 * sizeof(T));
+#pragma unroll
+                            for (int n = 0; n < 3; ++n)
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) *reinterpret_cast<T*>(dst + (n * 4 + reg) * 64 * sizeof(T)) = acc[m][n][reg];
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        const int m = 2 * round + mm;
+                        if (wave == m) {
+                            const unsigned char* src = crb_smem + red_base + unsigned(mm * 3 * 12 * 64 * sizeof(T));
+#pragma unroll
+                            for (int n = 0; n < 3; ++n)
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) {
+                                    T sum = acc[m][n][reg];
+#pragma unroll
+                                    for (int k = 0; k < 3; ++k) sum += *reinterpret_cast<const T*>(src + (k * 12 + n * 4 + reg) * 64 * sizeof(T));
+                                    // row 16 m + (lane >> 4) + 4 reg, column 48 y + 16 n + fi   (m = wave here)
+                                    const T v = HAS_REF ? sum : -sum;
+                                    __builtin_amdgcn_raw_buffer_store_b64(
+                                        loop_u2{unsigned(__double2loint(v)), unsigned(__double2hiint(v))}, urs,
+                                        u_base + unsigned((4 * reg * NCOL + 16 * n) * sizeof(T)), 0, LOOP_SC1);
+                                }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // (the exchange columns share the scratch: their "no neighbour" entries are zeroed again)
+                if (LOGNW > 0 && tl == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0); ++k) lds3[size_t(k) * (NTB + 1) + NTB] = T(0);
+                }
+                if (!handoff()) return;
+
+                // ======================================================== stage phase: whole beams
+                const double ts = (s == 0) ? tc : ((s == 3) ? t_full : t_half);
+                const bool imp_on = ts < p.duration;
+                const T w = (s == 0 || s == 3) ? T(1) : T(2);
+                const T cs = (s == 2) ? dt : hdt;
+#pragma unroll 1
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int bl = pass * BPP + sub, beam = rb * 64 + y * BPW + bl;
+                    const int li = pass * 256 + t;
+                    T sq[3], sv[3], uin[3], x0q[3], x0v[3], aq[3], av[3];
+                    loop_ld6(xrs, e_off(bl), sq, sv);
+                    loop_ld3(urs, u_off(bl), uin);
+                    t2* x0p = reinterpret_cast<t2*>(x0mine + size_t(pass) * 256 * 6);
+                    {
+                        const t2 v0 = x0p[0], v1 = x0p[1], v2 = x0p[2];
+                        x0q[0] = v0[0]; x0q[1] = v0[1]; x0q[2] = v1[0]; x0v[0] = v1[1]; x0v[1] = v2[0]; x0v[2] = v2[1];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        aq[c] = s ? accs[size_t(c) * NLI + li] : T(0);
+                        av[c] = s ? accs[size_t(3 + c) * NLI + li] : T(0);
+                    }
+                    T amp = T(0), gx = p.gx, gy = p.gy;
+                    if (beam < p.B) {
+                        if (p.amp && slot_ok && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
+                        if (GRAV && p.gvec) { gx = p.gvec[2 * size_t(beam)]; gy = p.gvec[2 * size_t(beam) + 1]; }
+                    }
+                    T uadd[3], a[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) uadd[c] = uin[c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp;
+                    // (beams past the ensemble's end run on zeros: finite, never stored into the state)
+                    loop_rhs<T, LV, LOGNW, GRAV, EM>(tab, my_kind, gx, gy, corrected, drag_on, lds3, tl, lane, j, S, slot_ok, sq, sv, uadd, a);
+                    T nq[3], nv[3], oq[3], ov[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        nq[c] = aq[c] + w * sv[c];
+                        nv[c] = av[c] + w * a[c];
+                        oq[c] = (s < 3) ? x0q[c] + cs * sv[c] : x0q[c] + dt6 * nq[c];
+                        ov[c] = (s < 3) ? x0v[c] + cs * a[c] : x0v[c] + dt6 * nv[c];
+                    }
+                    if (s < 3) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { accs[size_t(c) * NLI + li] = nq[c]; accs[size_t(3 + c) * NLI + li] = nv[c]; }
+                    } else if (!last_step) {
+                        x0p[0] = t2{oq[0], oq[1]}; x0p[1] = t2{oq[2], ov[0]}; x0p[2] = t2{ov[1], ov[2]};
+                    } else if (slot_ok && beam < p.B) {   // the rollout's last stage: the state back into the device layout
+                        typedef T rec4 __attribute__((ext_vector_type(4)));
+                        T* dst = p.x + size_t(beam) * 2 * plane + size_t(j + p.off) * 4;
+                        *reinterpret_cast<rec4*>(dst) = rec4{oq[0], oq[1], oq[2], T(0)};
+                        *reinterpret_cast<rec4*>(dst + plane) = rec4{ov[0], ov[1], ov[2], T(0)};
+                    }
+                    if (s == 3 && last_step) continue;   // (nobody reads a stage state after the rollout's last stage)
+                    if (HAS_REF) {
+                        T eq[3] = {T(0), T(0), T(0)}, ev[3] = {T(0), T(0), T(0)};
+                        if (beam < p.B) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                if (red[c] >= 0) {
+                                    eq[c] = P.ref[size_t(beam) * 2 * P.n_red + red[c]] - oq[c];
+                                    ev[c] = P.ref[size_t(beam) * 2 * P.n_red + P.n_red + red[c]] - ov[c];
+                                }
+                        }
+                        loop_st6(ers, e_off(bl), eq, ev);
+                        loop_st6(xrs, e_off(bl), oq, ov);
+                    } else {
+                        loop_st6(ers, e_off(bl), oq, ov);
+                    }
+                }
+                // (the rollout's last stage hands nothing on: the next row block's first hand-off orders the rest)
+                if (!(s == 3 && last_step)) {
+                    if (!handoff()) return;
+                }
+            }
+            tc = t_full;
+        }
+        if (p.n_steps == 0) continue;
+    }
+}
+
+}  // namespace crb

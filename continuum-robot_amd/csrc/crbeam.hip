@@ -12,6 +12,7 @@
 #include "../../include/crbeam.h"
 #include "crb_kernels.h"
 #include "crb_lean_launch.h"
+#include "crb_loop_launch.h"
 
 using namespace crb;
 
@@ -105,6 +106,7 @@ struct crb_plan {
     mutable hipEvent_t aux_in = nullptr, aux_out = nullptr;
     mutable hipGraphExec_t step_exec = nullptr;
     mutable std::vector<uint64_t> step_key;
+    mutable bool loop_used = false;   // the last crb_step_rk4_feedback ran the persistent stepper (its work buffer holds a status word)
 };
 
 extern "C" int crb_version(void) { return CRB_VERSION; }
@@ -1371,10 +1373,50 @@ extern "C" int crb_step_implicit(const crb_plan* p, void* x, double t0, double h
 static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage, int stage,
                          double t_stage, const double* t_dev, double dt, const crb_input_desc* in, void* stream);
 
+namespace {
+// The persistent closed-loop stepper (crb_loop.h): fp64 plans with one table set and one free-DOF set, beams of 33 .. 128
+// thread-carried nodes, gravity absent or of the plain cantilever's form, no held input.  CRB_LOOP=0 / 1 in the
+// environment: never / whenever eligible; unset: ensembles of at least LOOP_MIN_BEAMS beams (a group of workgroups owns
+// 64 beams: small ensembles leave most of the chip idle and are faster through the stage-split launches).
+constexpr int LOOP_MIN_BEAMS = 512;
+int loop_nb(const crb_plan* p) { return p->lognw == 1 ? 8 : 4; }
+bool loop_shape_ok(const crb_plan* p) {
+    const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
+    return p->dtype == CRB_F64 && !p->mixed_topology && p->slot_stride == 0 && p->lv_stride == 0 && p->fin_stride == 0 && p->G == 1 &&
+           (p->lognw == 0 || p->lognw == 1) && p->NT == (64 << p->lognw) && p->S > 32 && (p->levels == 5 || p->levels == 6) &&
+           (!grav || p->canonical_gravity);
+}
+bool loop_eligible(const crb_plan* p, const crb_input_desc* in) {
+    if (!loop_shape_ok(p) || (in && in->f_held)) return false;
+    const char* env = std::getenv("CRB_LOOP");
+    if (env) return std::atoi(env) != 0;
+    return p->B >= LOOP_MIN_BEAMS;
+}
+}  // namespace
+
 extern "C" size_t crb_feedback_work_bytes(const crb_plan* p) {
     if (!p) return 0;
     const size_t state = size_t(p->B) * 2 * p->n_node * 4 * (p->dtype == CRB_F64 ? sizeof(double) : sizeof(float)), force = state / 2;
-    return 3 * state + force + 256;   // + the device clock of the replayed step
+    size_t need = 3 * state + force + 256;   // + the device clock of the replayed step
+    if (loop_shape_ok(p)) {
+        const int n_rb = (p->B + 63) / 64;
+        const size_t loop = crb::loop_work_layout(loop_nb(p), n_rb < crb::LOOP_MAX_GROUPS ? n_rb : crb::LOOP_MAX_GROUPS).total;
+        if (loop > need) need = loop;
+    }
+    return need;
+}
+
+extern "C" int crb_feedback_status(const crb_plan* p, const void* work, int32_t* status, void* stream) {
+    if (int rc = need_device(p, "crb_feedback_status")) return rc;
+    if (!work || !status) return fail(CRB_EINVAL, "crb_feedback_status: null pointer");
+    *status = 0;
+    if (!p->loop_used) return CRB_OK;   // (only the persistent stepper keeps a status word)
+    unsigned words[2] = {0, 0};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(words, work, sizeof(words), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *status = int32_t(words[1]);
+    return CRB_OK;
 }
 
 namespace {
@@ -1459,6 +1501,57 @@ extern "C" int crb_step_rk4_feedback(const crb_plan* p, void* x, double t0, doub
     if (int rc = need_device(p, "crb_step_rk4_feedback")) return rc;
     if (!x || !gain || !work) return fail(CRB_EINVAL, "crb_step_rk4_feedback: null pointer");
     if (n_steps < 0 || !(dt > 0)) return fail(CRB_EINVAL, "crb_step_rk4_feedback: n_steps >= 0 and dt > 0 required");
+    p->loop_used = false;
+    if (loop_eligible(p, in)) {
+        if (in && in->kind == CRB_INPUT_IMPULSE &&
+            (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp || !p->any_free[3 * in->node + in->dof]))
+            return fail(CRB_EINVAL, "crb_step_rk4_feedback: bad impulse description");
+        if (in && in->kind != CRB_INPUT_IMPULSE && in->kind != CRB_INPUT_NONE)
+            return fail(CRB_EINVAL, "crb_step_rk4_feedback: unknown input kind");
+        if (t_end) {
+            double t = t0;
+            for (int i = 0; i < n_steps; ++i) t = t + dt;
+            *t_end = t;
+        }
+        if (n_steps == 0) return CRB_OK;
+        if (int rc = ensure_red_map(p)) return rc;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int nb = loop_nb(p), n_rb = (p->B + 63) / 64;
+        const crb::LoopWork lay = crb::loop_work_layout(nb, n_rb < crb::LOOP_MAX_GROUPS ? n_rb : crb::LOOP_MAX_GROUPS);
+        char* w = static_cast<char*>(work);
+        crb::LoopParams<double> P;
+        std::memset(&P, 0, sizeof(P));
+        P.k = base_params<double>(p);
+        P.k.x = static_cast<double*>(x);
+        P.k.t0 = t0; P.k.dt = dt; P.k.n_steps = n_steps;
+        if (in && in->kind == CRB_INPUT_IMPULSE) {
+            P.k.amp = static_cast<const double*>(in->amp);
+            P.k.imp_slot = in->node - p->off; P.k.imp_dof = in->dof; P.k.duration = in->duration;
+            P.k.imp_node_b = in->node_b;
+        }
+        P.ref = static_cast<const double*>(ref);
+        P.red_map = p->d_red_map;
+        P.n_red = p->n_free;
+        P.sync = reinterpret_cast<unsigned*>(w);
+        P.kfrag = reinterpret_cast<const double*>(w + lay.kfrag);
+        P.ebuf = reinterpret_cast<double*>(w + lay.ebuf);
+        P.xnbuf = reinterpret_cast<double*>(w + lay.xnbuf);
+        P.ubuf = reinterpret_cast<double*>(w + lay.ubuf);
+        P.x0buf = reinterpret_cast<double*>(w + lay.x0buf);
+        P.n_rb = n_rb;
+        const char* fenv = std::getenv("CRB_LOOP_FENCES");
+        P.fences = fenv ? std::atoi(fenv) : 0;
+        const char* tenv = std::getenv("CRB_LOOP_TIMEOUT_MS");
+        P.timeout = (unsigned long long)(tenv ? std::atol(tenv) : 2000) * 100000ull;   // 100 MHz ticks
+        // every polled word starts at zero, in every call
+        HIP_TRY(hipMemsetAsync(w, 0, size_t(crb::LOOP_SYNC_WORDS) * sizeof(unsigned), st));
+        const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
+        const hipError_t e = p->lognw == 1 ? crb::launch_loop_long(P, static_cast<const double*>(gain), p->levels, grav, p->elem_mode, st)
+                                           : crb::launch_loop_short(P, static_cast<const double*>(gain), p->levels, grav, p->elem_mode, st);
+        if (e != hipSuccess) return fail(CRB_EHIP, std::string("crb_step_rk4_feedback (persistent stepper): ") + hipGetErrorString(e));
+        p->loop_used = true;
+        return CRB_OK;
+    }
     if (fused_feedback_eligible(p, in)) {
         if (in && in->kind == CRB_INPUT_IMPULSE &&
             (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp || !p->any_free[3 * in->node + in->dof]))

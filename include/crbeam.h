@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRB_VERSION 101
+#define CRB_VERSION 102
 
 enum { CRB_OK = 0, CRB_EINVAL = -1, CRB_EHIP = -2, CRB_ENODEV = -3, CRB_EUNSUPPORTED = -4 };
 enum { CRB_F64 = 0, CRB_F32 = 1 };
@@ -265,8 +265,16 @@ int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void
  * Beams that live in one wave (fewer than 64 thread-carried nodes: the reference's own LQR example has 6 elements)
  * and whose gain fits LDS take ONE launch for the whole rollout instead: the general stepper with the gain resident in
  * LDS and K (r - x) formed per stage by the node threads (12 instead of 36 us per step at 6 elements, 21 instead of
- * 40 - 48 at 16).  CRB_FUSED_FEEDBACK=0 / 1 in the environment forces the stage-split / the fused form. */
+ * 40 - 48 at 16).  CRB_FUSED_FEEDBACK=0 / 1 in the environment forces the stage-split / the fused form.
+ * Large ensembles of beams with 33 .. 128 thread-carried nodes (fp64, one table set) take ONE persistent launch for the
+ * whole rollout (csrc/crb_loop.h): groups of workgroups own 64 beams each, keep their slice of the gain in registers,
+ * and alternate between the fp64-MFMA product and the stage arithmetic, handing tiles to each other through L2.
+ * CRB_LOOP=0 / 1 forces the stage-split / the persistent form.  A hand-off that does not complete within
+ * CRB_LOOP_TIMEOUT_MS (default 2000) makes every workgroup leave; crb_feedback_status reports it. */
 size_t crb_feedback_work_bytes(const crb_plan* plan);
+/* *status = 0, or (group + 1) of the first hand-off of the last crb_step_rk4_feedback call on `work` that timed out (the
+ * state is then unusable).  Synchronises `stream`. */
+int crb_feedback_status(const crb_plan* plan, const void* work, int32_t* status, void* stream);
 int crb_step_rk4_feedback(const crb_plan* plan, void* x, double t0, double dt, int n_steps, const void* gain,
                           const void* ref, const crb_input_desc* input, void* work, double* t_end, void* stream);
 

@@ -36,7 +36,7 @@ def ensemble(cols, n_beams, kw=None, dtype=None, node_bc=None, corrected_axial=F
 def test_native_library_is_the_loaded_path():
     from continuum_robot import _native as nat
 
-    assert nat.load().crb_version() == 101
+    assert nat.load().crb_version() == 102
     assert torch.cuda.is_available()
 
 
