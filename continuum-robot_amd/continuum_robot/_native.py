@@ -269,6 +269,10 @@ class Plan:
         x = np.ascontiguousarray(x_red, dtype=np.float64)
         out = np.empty_like(x)
         u = None if u_red is None else np.ascontiguousarray(u_red, dtype=np.float64)
+        # (the C entry point takes bare pointers and copies n_beams * 2n / n_beams * n doubles: sizes are checked here)
+        if x.size != self.n_beams * 2 * self.n_free0 or (u is not None and u.size != self.n_beams * self.n_free0):
+            raise ValueError(f"rhs_host: expected {self.n_beams} x {2 * self.n_free0} state and {self.n_beams} x {self.n_free0} "
+                             f"input values, got {x.size}" + ("" if u is None else f" and {u.size}"))
         rc = self._rhs_host(self.h, x.ctypes.data, u.ctypes.data if u is not None else None, out.ctypes.data)
         if rc:
             check(rc)
@@ -276,6 +280,8 @@ class Plan:
 
     def internal_force_host(self, q_red):
         q = np.ascontiguousarray(q_red, dtype=np.float64)
+        if q.size != self.n_beams * self.n_free0:
+            raise ValueError(f"internal_force_host: expected {self.n_beams} x {self.n_free0} positions, got {q.size}")
         out = np.empty_like(q)
         check(load().crb_internal_force_host(self.h, q.ctypes.data, out.ctypes.data))
         return out

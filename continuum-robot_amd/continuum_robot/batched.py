@@ -165,11 +165,12 @@ class BeamEnsemble:
         if self.mixed_topology:
             self.free_index_per_beam = [p.beam_free_index(b) for b in range(n_beams)]
             self.n_per_beam = np.array([fi.size for fi in self.free_index_per_beam])
-            self.n_elem_per_beam = np.array([p.beam_info(b)[0] for b in range(n_beams)])
         else:
             self.free_index_per_beam = [self.free_index] * n_beams
             self.n_per_beam = np.full(n_beams, self.n)
-            self.n_elem_per_beam = np.full(n_beams, self.n_elem)
+        # (element counts can differ with ONE free-DOF set: a longer beam whose extra nodes are all FIXED)
+        self.n_elem_per_beam = (np.array([p.beam_info(b)[0] for b in range(n_beams)]) if p.per_beam
+                                else np.full(n_beams, self.n_elem))
         self.state = torch.zeros((n_beams, 2, self.n_node, 4), dtype=dtype, device=self.device)
         self.time = 0.0
         self._lib = nat.load()

@@ -43,6 +43,9 @@ namespace crb {
 constexpr int LOOP_SYNC_WORDS = 2048;   // 8 KB at the start of the work buffer: [0] ticket, [1] error, counters at [32 + 32 g]
 constexpr int LOOP_MAX_GROUPS = (LOOP_SYNC_WORDS - 32) / 32;
 constexpr int LOOP_SC1 = 16;            // aux bit of the raw buffer intrinsics: sc1 (write-through store / L1-bypassing load)
+#ifndef CRB_LOOP_PROF                   // 1: every workgroup adds its time per phase (100 MHz ticks) to sync words [2 .. 13] (tuning builds)
+#define CRB_LOOP_PROF 0
+#endif
 #ifndef CRB_LOOP_DEPTH                  // slot pairs of A fragments in flight ahead of the MFMAs (24 VGPRs each)
 #define CRB_LOOP_DEPTH 4
 #endif
@@ -54,10 +57,10 @@ struct LoopParams {
     const T* ref;              // [B][2n] reduced, or nullptr (= regulation to 0)
     const int32_t* red_map;    // [3 n_node]: reduced index of a full DOF or -1 (reference vectors, HAS_REF)
     int n_red;                 // n
-    T* ebuf;                   // [groups][SP][64][12]  stage state (HAS_REF: r - state) in fragment order
-    T* xnbuf;                  // HAS_REF only: the stage state itself, same order
+    T* ebuf;                   // [groups][SP][64][12]  stage state (HAS_REF: r - state) in fragment order: the GEMM's A operand
     T* ubuf;                   // [groups][64][48 NB]   feedback force per beam and padded slot DOF
-    T* x0buf;                  // [groups][64][16 NB][6] the step's start state, private to the workgroup that owns the beam
+    T* ownbuf;                 // [groups][64][16 NB][12] {step-start state, stage state} of every node, private to the workgroup
+                               // that owns the beam (plain accesses through L2; what is handed on goes to ebuf write-through)
     unsigned* sync;            // LOOP_SYNC_WORDS words, zeroed before the launch
     int n_rb, n_groups;        // row blocks of 64 beams; groups of NB workgroups in the grid
     int fences;                // 1: agent-scope release / acquire fences around every hand-off as well (debugging aid)
@@ -79,7 +82,7 @@ __host__ __device__ constexpr size_t loop_lds_bytes() {
     const size_t acc = size_t(6) * BPW * NTB * sizeof(T);
     const size_t tab = size_t(loop_tab_items<LV>()) * NTB * 2 * sizeof(T) + size_t(NTB) * sizeof(int32_t);
     const size_t red = size_t(6) * 3 * 4 * 64 * sizeof(T);
-    const size_t xch = size_t(BPP) * (9 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)) * (NTB + 1) * sizeof(T);
+    const size_t xch = size_t(BPP) * 11 * (NTB + 1) * sizeof(T);
     return acc + tab + ((red > xch ? red : xch) + 15) / 16 * 16 + 16;
 }
 
@@ -109,12 +112,23 @@ __device__ __forceinline__ void loop_st6(__amdgpu_buffer_rsrc_t r, unsigned off,
 }
 
 // The gain slice of a workgroup is 18 NB doubles per lane: 288 registers at NB = 8, more than the 256 accumulator
-// registers.  The matrix instruction is written out so that the register CLASS of every fragment is fixed -- all but the
-// last 3 * 6 NB - 128 in accumulator registers (which vector-ALU code cannot touch, so the stage phase cannot evict
-// them), the rest and the sums in vector registers.  Left to the compiler the sums take the accumulator file, a third of
-// the slice spills to scratch and the A loads sink to their first use.
+// registers.  The matrix instruction is written out so that the register CLASS of every fragment is fixed: the resident
+// fragments sit in accumulator registers (which vector-ALU code cannot touch, so the stage phase cannot evict them), the
+// sums and the streamed operands in vector registers.  Left to the compiler the sums take the accumulator file, a third
+// of the slice spills to scratch and the A loads sink to their first use.
+// Not all of it is resident: the last LOOP_BSTREAM k-steps of the third column tile are re-read from L2 in every GEMM
+// phase, riding in the A operand's register ring (coalesced 512-byte loads, +18 % on the A stream at 36 of 144) -- the
+// accumulator file then keeps room for what the stage phase parks there, instead of the compiler evicting fragments to
+// scratch.
+#ifndef CRB_LOOP_BSTREAM
+#define CRB_LOOP_BSTREAM 36
+#endif
 template <int NB>
-__host__ __device__ constexpr bool loop_b_in_vgpr(int n, int ks) { return n * 6 * NB + ks >= 128; }
+__host__ __device__ constexpr int loop_n_streamed() {   // k-steps of column tile 2 that are streamed (a multiple of 3: whole slot pairs)
+    return 18 * NB > 128 ? (CRB_LOOP_BSTREAM > 18 * NB - 126 ? CRB_LOOP_BSTREAM : 18 * NB - 126) : 0;
+}
+template <int NB>
+__host__ __device__ constexpr bool loop_b_streamed(int n, int ks) { return n == 2 && ks >= 6 * NB - loop_n_streamed<NB>(); }
 __device__ __forceinline__ void loop_mfma(bool B_IN_VGPR /* a constant once the loops are unrolled */, typename MfmaOps<double>::acc_t& c, double a, double b) {
     // (s_nop 1: a freshly copied operand may not feed the matrix pipe at once; the sum chains on itself without a wait)
     if (B_IN_VGPR) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
@@ -154,7 +168,7 @@ __device__ __forceinline__ void loop_rhs(const T* tab, int kind, T gx, T gy, boo
     typedef T t2 __attribute__((ext_vector_type(2)));
     auto item = [&](int k) { return *reinterpret_cast<const t2*>(tab + size_t(2 * k) * NT); };
     T* const ldsQ = lds3;                           // [3][NT+1]  stage positions
-    T* const ldsA = lds3 + 3 * size_t(NT + 1);      // [6][NT+1]  p0..2, fl0..2
+    T* const ldsA = lds3 + 3 * size_t(NT + 1);      // [8][NT+1]  p0..2, fl0..2, g0..1
     auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
     const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S;
     const int t_l1 = has_left ? thread_of(j - 1) : NULLT;
@@ -188,21 +202,20 @@ __device__ __forceinline__ void loop_rhs(const T* tab, int kind, T gx, T gy, boo
     for (int c = 0; c < 3; ++c) pp[c] = uadd[c] - fr[c];
     const t2 f4d = item(5 * LV + 2);   // [final 4, drag]
     pp[1] += drag_force<T>(drag_on ? f4d[1] : T(0), sv[1]);
-    if (GRAV) {   // gravity_forces.py:104-146 on the plain cantilever: segment j averages the rotations of slots j, j+1
+    // gravity_forces.py:104-146 on the plain cantilever: segment j averages the rotations of slots j, j+1 and loads slots j
+    // and j+1, so node j carries g(segment j) + g(segment j-1).  One sincos per thread: a thread evaluates ITS segment and
+    // takes the left one's from the left neighbour (lane shift, or a column of the exchange round below).
+    T g_own[2] = {T(0), T(0)};
+    if (GRAV) {
         const t2 hm = item(5 * LV + 6);   // [half mass of segment j, of segment j-1]
-        T g_own[2], g_left[2];
         gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], gx, gy, hm[0], g_own);
-        if (LOGNW == 0) {
-            g_left[0] = lane_lower<T, 1>(g_own[0], lane);
-            g_left[1] = lane_lower<T, 1>(g_own[1], lane);
-        } else {
-            gravity_segment<T>(T(0.5) * (qL[2] + sq[2]), gx, gy, hm[1], g_left);
-        }
-        pp[0] += g_own[0] + g_left[0];
-        pp[1] += g_own[1] + g_left[1];
     }
     T r[3], rlo[3], rhi[3];
     if (LOGNW == 0) {
+        if (GRAV) {
+            pp[0] += g_own[0] + lane_lower<T, 1>(g_own[0], lane);
+            pp[1] += g_own[1] + lane_lower<T, 1>(g_own[1], lane);
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
@@ -210,15 +223,26 @@ __device__ __forceinline__ void loop_rhs(const T* tab, int kind, T gx, T gy, boo
             rhi[c] = lane_higher<T, 1>(r[c], lane);
         }
     } else {
+        // round A: {p without gravity, f_left, own segment's gravity}; a node's p is completed from its own and its left
+        // neighbour's segment wherever it is needed (this node, and both stride-1 neighbours for level 0)
         auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
+        const int t_l2 = (valid && j >= 2) ? thread_of(j - 2) : NULLT;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { col(c, tl) = pp[c]; col(3 + c, tl) = fl[c]; }
+        if (GRAV) { col(6, tl) = g_own[0]; col(7, tl) = g_own[1]; }
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            rlo[c] = col(c, t_l1) - fl[c];
-            r[c] = pp[c] - col(3 + c, t_r1);
-            rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+            T p_l = col(c, t_l1), p_o = pp[c], p_r = col(c, t_r1);
+            if (GRAV && c < 2) {
+                const T g_l1 = col(6 + c, t_l1);
+                p_l += g_l1 + col(6 + c, t_l2);
+                p_o += g_own[c] + g_l1;
+                p_r += col(6 + c, t_r1) + g_own[c];
+            }
+            rlo[c] = p_l - fl[c];
+            r[c] = p_o - col(3 + c, t_r1);
+            rhi[c] = p_r - col(3 + c, t_r2);
         }
     }
 #pragma unroll
@@ -259,7 +283,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     static_assert(SPAD == NTB, "one thread per padded slot");
     static_assert(NPASS * BPP == BPW && BPW * NB == 64, "beams of a row block divide evenly");
     static_assert(D >= 2 && D <= SPW, "pipeline depth");
-    constexpr int XCH = (9 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)) * (NTB + 1);   // exchange doubles per beam in flight
+    constexpr int XCH = 11 * (NTB + 1);   // exchange doubles per beam in flight: q (3), p (3), f_left (3), segment gravity (2)
     constexpr int ITEMS = loop_tab_items<LV>();
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const accs = reinterpret_cast<T*>(crb_smem);                 // [6][NLI]: RK4 accumulator q, v
@@ -280,8 +304,16 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     unsigned* const counter = P.sync + 32 + 32 * group;
     unsigned* const errw = P.sync + 1;
     unsigned arrivals = 0;   // hand-offs this group has been through
-    // hand-off: true = every workgroup of the group has arrived; false = give up (timeout or another group's error)
-    auto handoff = [&]() -> bool {
+#if CRB_LOOP_PROF
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memrealtime();
+#define CRB_LOOP_STAMP(k) do { const unsigned long long now__ = __builtin_amdgcn_s_memrealtime(); prof[k] += now__ - prof_t; prof_t = now__; } while (0)
+#else
+#define CRB_LOOP_STAMP(k) do { } while (0)
+#endif
+    // hand-off in two halves.  arrive: this workgroup's stores are out, one lane says so.  wait: true = every workgroup of
+    // the group has arrived; false = give up (timeout, or another group's error).  What a workgroup loads between the
+    // two must be its own data.
+    auto arrive = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
         __syncthreads();
         ++arrivals;
@@ -291,6 +323,10 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto wait = [&]() -> bool {
+        if (t == 0) {
             const unsigned target = arrivals * NB;
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             unsigned ok = 1;
@@ -306,26 +342,28 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                     }
                 }
             }
-            if (P.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (P.fences) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             sh[1] = ok;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         return sh[1] != 0u;
     };
+    auto handoff = [&]() -> bool { arrive(); return wait(); };
 
     // ---- GEMM role of this thread: wave = K quarter (slot pairs SPW wave ...), lane = (row / column fi, k quarter kq)
     const int fi = lane & 15, kq = lane >> 4;
-    // gain slice in registers: Bf[n][3 spl + tt] = K[row 48 y + 16 n + fi][column of (slot 2 sp + (kq >> 1), plane kq & 1, dof tt)],
-    // prepared in exactly this order by crb_loop_gain_kernel: coalesced loads, once per launch
+    // gain slice: Bf[n][3 spl + tt] = K[row 48 y + 16 n + fi][column of (slot 2 sp + (kq >> 1), plane kq & 1, dof tt)], prepared
+    // in exactly this order by crb_loop_gain_kernel (coalesced loads).  Resident fragments: accumulator registers, for the
+    // whole launch; streamed ones (loop_b_streamed): re-read with the A operand in every GEMM phase.
+    const T* const bsrc = P.kfrag + (size_t(y) * 4 + wave) * 3 * KSW * 64 + lane;
     T Bf[3][KSW];
-    {
-        const T* src = P.kfrag + (size_t(y) * 4 + wave) * 3 * KSW * 64 + lane;
 #pragma unroll
-        for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < 3; ++n)
 #pragma unroll
-            for (int ks = 0; ks < KSW; ++ks) Bf[n][ks] = src[size_t(n * KSW + ks) * 64];
-    }
+        for (int ks = 0; ks < KSW; ++ks) Bf[n][ks] = loop_b_streamed<NB>(n, ks) ? T(0) : bsrc[size_t(n * KSW + ks) * 64];
     // ---- stage role: beam `sub` of the pass, slot j
     const int sub = wave >> LOGNW, wib = wave & ((1 << LOGNW) - 1), tl = (wib << 6) | lane;
     const int S = p.S;
@@ -369,19 +407,43 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     }
     const __amdgpu_buffer_rsrc_t ers =
         __builtin_amdgcn_make_buffer_rsrc(P.ebuf + size_t(group) * loop_ebuf_elems<NB>(), 0, unsigned(loop_ebuf_elems<NB>() * sizeof(T)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrs =
-        __builtin_amdgcn_make_buffer_rsrc((HAS_REF ? P.xnbuf : P.ebuf) + size_t(group) * loop_ebuf_elems<NB>(), 0,
-                                          unsigned(loop_ebuf_elems<NB>() * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t urs =
         __builtin_amdgcn_make_buffer_rsrc(P.ubuf + size_t(group) * loop_ubuf_elems<NB>(), 0, unsigned(loop_ubuf_elems<NB>() * sizeof(T)), 0x00020000);
-    // the step's start state of this thread's beams: [pass][256 threads][6], nobody else's business (plain accesses)
-    T* const x0mine = P.x0buf + ((size_t(group) * NB + y) * NLI + t) * 6;
+    // this thread's nodes in the private buffer: [pass][256 threads][x0 q, x0 v, xs q, xs v], as a byte offset (< 4 GB) from its
+    // start (an offset, not a pointer, is what gets laundered below: a laundered pointer loses its address space)
+    const unsigned mine = unsigned(((size_t(group) * NB + y) * NLI + t) * 12 * sizeof(T));
+    auto own_at = [&](unsigned off, int pass) { return reinterpret_cast<t2*>(reinterpret_cast<unsigned char*>(P.ownbuf) + off + unsigned(pass * 256 * 12 * sizeof(T))); };
     // byte offsets: this lane's first A fragment; this thread's stage record / force of beam `bl` of the workgroup
     const unsigned a_off0 = unsigned((((SPW * wave) * 64 + fi) * 12 + 3 * kq) * sizeof(T));
     auto e_off = [&](int bl) { return unsigned((((j >> 1) * 64 + (y * BPW + bl)) * 12 + (j & 1) * 6) * sizeof(T)); };
     auto u_off = [&](int bl) { return unsigned(((y * BPW + bl) * NCOL + 3 * j) * sizeof(T)); };
     const int kind = 0;   // (set after the tables' barrier below)
     (void)kind;
+
+    // inputs of one pass of the stage phase: this thread's stage record and step-start record (private buffer), its
+    // feedback force, its beam's gravity vector (and its entries of the reference)
+    struct PassIn { T sq[3], sv[3], x0q[3], x0v[3], uin[3], gx, gy; };
+    struct PassRef { T rq[3], rv[3]; };   // (its own object: copied only where a reference exists)
+    auto load_own = [&](PassIn& in, PassRef& rf, unsigned own, int pass, int rb) {
+        const t2* o = own_at(own, pass);
+        const t2 v0 = o[0], v1 = o[1], v2 = o[2], v3 = o[3], v4 = o[4], v5 = o[5];
+        in.x0q[0] = v0[0]; in.x0q[1] = v0[1]; in.x0q[2] = v1[0]; in.x0v[0] = v1[1]; in.x0v[1] = v2[0]; in.x0v[2] = v2[1];
+        in.sq[0] = v3[0]; in.sq[1] = v3[1]; in.sq[2] = v4[0]; in.sv[0] = v4[1]; in.sv[1] = v5[0]; in.sv[2] = v5[1];
+        in.gx = p.gx; in.gy = p.gy;
+        if ((GRAV && p.gvec) || HAS_REF) {
+            const int beam = rb * 64 + y * BPW + pass * BPP + sub;
+            const bool real = beam < p.B;
+            if (GRAV && p.gvec && real) { in.gx = p.gvec[2 * size_t(beam)]; in.gy = p.gvec[2 * size_t(beam) + 1]; }
+            if (HAS_REF) {
+                const T* rrow = P.ref + size_t(real ? beam : 0) * 2 * P.n_red;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    rf.rq[c] = (red[c] >= 0 && real) ? rrow[red[c]] : T(0);
+                    rf.rv[c] = (red[c] >= 0 && real) ? rrow[P.n_red + red[c]] : T(0);
+                }
+            }
+        }
+    };
 
     for (int rb = group; rb < P.n_rb; rb += P.n_groups) {
         // ---- prologue: the workgroup's beams into its private start-state buffer and into the fragment buffer
@@ -395,8 +457,9 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { xq[c] = p.x[xoff + c] * sc.mask[c]; xv[c] = p.x[xoff + plane + c] * sc.mask[c]; }
             }
-            t2* x0p = reinterpret_cast<t2*>(x0mine + size_t(pass) * 256 * 6);
-            x0p[0] = t2{xq[0], xq[1]}; x0p[1] = t2{xq[2], xv[0]}; x0p[2] = t2{xv[1], xv[2]};
+            t2* own = own_at(mine, pass);
+            own[0] = t2{xq[0], xq[1]}; own[1] = t2{xq[2], xv[0]}; own[2] = t2{xv[1], xv[2]};
+            own[3] = t2{xq[0], xq[1]}; own[4] = t2{xq[2], xv[0]}; own[5] = t2{xv[1], xv[2]};
             if (HAS_REF) {
                 T eq[3] = {T(0), T(0), T(0)}, ev[3] = {T(0), T(0), T(0)};
                 if (beam < p.B) {
@@ -408,13 +471,19 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                         }
                 }
                 loop_st6(ers, e_off(bl), eq, ev);
-                loop_st6(xrs, e_off(bl), xq, xv);
             } else {
                 loop_st6(ers, e_off(bl), xq, xv);
             }
         }
         if (!handoff()) return;   // (its barriers also publish the tables in LDS)
         const int my_kind = kinds[tl];
+        T amps[NPASS];   // impulse amplitude of this thread's node in each of its beams (0 everywhere but at the forced node)
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int beam = rb * 64 + y * BPW + pass * BPP + sub;
+            amps[pass] = T(0);
+            if (p.amp && slot_ok && beam < p.B && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amps[pass] = p.amp[beam];
+        }
 
         double tc = p.t0;
 #pragma unroll 1
@@ -424,6 +493,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
 #pragma unroll 1
             for (int s = 0; s < 4; ++s) {
                 // ======================================================== GEMM phase: U tile = E . Kslice^T
+                CRB_LOOP_STAMP(5);
                 acc4 acc[4][3];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -432,10 +502,19 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                 {
                     // ring of D register sets: the loads of slot pairs spl + 1 .. spl + D - 1 fly while spl is multiplied
                     // (pinned by scheduling barriers: left alone, the scheduler sinks every load to its first use)
-                    T af[D][4][3];
+                    T af[D][4][3], bs[D][3];
+                    // (the streamed fragments by byte offset from the kernel argument: an offset can be laundered -- so that these
+                    //  loads are not hoisted out of the step loop into registers -- without the pointer losing its address space)
+                    unsigned b_off = unsigned((((size_t(y) * 4 + wave) * 3 + 2) * KSW * 64 + lane) * sizeof(T));
+                    asm volatile("" : "+v"(b_off));
+                    const T* bl = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(P.kfrag) + b_off);
                     auto fetch = [&](int spl) {
 #pragma unroll
                         for (int m = 0; m < 4; ++m) loop_ld3(ers, a_off0 + unsigned((spl * 64 + 16 * m) * 12 * sizeof(T)), af[spl % D][m]);
+                        if (loop_b_streamed<NB>(2, 3 * spl)) {
+#pragma unroll
+                            for (int tt = 0; tt < 3; ++tt) bs[spl % D][tt] = bl[size_t(3 * spl + tt) * 64];
+                        }
                     };
 #pragma unroll
                     for (int d = 0; d < D - 1; ++d) fetch(d);
@@ -448,7 +527,10 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
 #pragma unroll
                             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                                for (int n = 0; n < 3; ++n) loop_mfma(loop_b_in_vgpr<NB>(n, 3 * spl + tt), acc[m][n], af[spl % D][m][tt], Bf[n][3 * spl + tt]);
+                                for (int n = 0; n < 3; ++n) {
+                                    const bool streamed = loop_b_streamed<NB>(n, 3 * spl + tt);
+                                    loop_mfma(streamed, acc[m][n], af[spl % D][m][tt], streamed ? bs[spl % D][tt] : Bf[n][3 * spl + tt]);
+                                }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     // (an MFMA's result is readable by other instructions only some cycles after issue; nothing pads that for asm)
@@ -456,6 +538,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                                  : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]),
                                    "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]));
                 }
+                CRB_LOOP_STAMP(0);
                 // ---- split-K: wave w owns row tile m = w; partial tiles change hands through LDS, two owners per round.
                 // (addresses are formed from ONE laundered base per use: hoisted out of the step loop, the 100-odd
                 //  distinct addresses of this block would each take a register and end in scratch)
@@ -502,11 +585,28 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                 // (the exchange columns share the scratch: their "no neighbour" entries are zeroed again)
                 if (LOGNW > 0 && tl == 0) {
 #pragma unroll
-                    for (int k = 0; k < 9 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0); ++k) lds3[size_t(k) * (NTB + 1) + NTB] = T(0);
+                    for (int k = 0; k < 11; ++k) lds3[size_t(k) * (NTB + 1) + NTB] = T(0);
                 }
-                if (!handoff()) return;
-
+                CRB_LOOP_STAMP(1);
                 // ======================================================== stage phase: whole beams
+                // A wave's memory counter retires in order and a write-through store takes over a microsecond to be
+                // acknowledged, so no wait may sit between a pass's stores and the next pass's loads: the inputs of pass
+                // p + 1 are requested at the top of pass p (ahead of p's stores; they are waited for at the top of p + 1,
+                // with p's stores still in flight behind them), and nothing else in a pass touches the counter -- no
+                // spill reloads (the register budget of this phase is why part of the gain slice is streamed), no
+                // loads of per-beam constants.  The workgroup's own records of the first pass are requested while it
+                // waits for the other workgroups' tiles.
+                PassIn cur, nxt;
+                PassRef cur_ref, nxt_ref;
+                // (bases laundered per stage: hoisted out of the step loop, every address below would hold a register)
+                unsigned e_base = e_off(sub), ub = u_off(sub), acc_base = unsigned(reinterpret_cast<unsigned char*>(accs) - crb_smem) + unsigned(t) * unsigned(sizeof(T));
+                unsigned own = mine;
+                asm volatile("" : "+v"(e_base), "+v"(ub), "+v"(acc_base), "+v"(own));
+                arrive();
+                load_own(cur, cur_ref, own, 0, rb);
+                if (!wait()) return;
+                loop_ld3(urs, ub, cur.uin);
+                CRB_LOOP_STAMP(2);
                 const double ts = (s == 0) ? tc : ((s == 3) ? t_full : t_half);
                 const bool imp_on = ts < p.duration;
                 const T w = (s == 0 || s == 3) ? T(1) : T(2);
@@ -514,75 +614,77 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
 #pragma unroll 1
                 for (int pass = 0; pass < NPASS; ++pass) {
                     const int bl = pass * BPP + sub, beam = rb * 64 + y * BPW + bl;
-                    const int li = pass * 256 + t;
-                    T sq[3], sv[3], uin[3], x0q[3], x0v[3], aq[3], av[3];
-                    loop_ld6(xrs, e_off(bl), sq, sv);
-                    loop_ld3(urs, u_off(bl), uin);
-                    t2* x0p = reinterpret_cast<t2*>(x0mine + size_t(pass) * 256 * 6);
-                    {
-                        const t2 v0 = x0p[0], v1 = x0p[1], v2 = x0p[2];
-                        x0q[0] = v0[0]; x0q[1] = v0[1]; x0q[2] = v1[0]; x0v[0] = v1[1]; x0v[1] = v2[0]; x0v[2] = v2[1];
+                    nxt = cur;
+                    if (HAS_REF) nxt_ref = cur_ref;
+                    if (pass + 1 < NPASS) {
+                        load_own(nxt, nxt_ref, own, pass + 1, rb);
+                        loop_ld3(urs, ub + unsigned((pass + 1) * BPP * NCOL * sizeof(T)), nxt.uin);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    T amp = amps[0];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        aq[c] = s ? accs[size_t(c) * NLI + li] : T(0);
-                        av[c] = s ? accs[size_t(3 + c) * NLI + li] : T(0);
-                    }
-                    T amp = T(0), gx = p.gx, gy = p.gy;
-                    if (beam < p.B) {
-                        if (p.amp && slot_ok && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
-                        if (GRAV && p.gvec) { gx = p.gvec[2 * size_t(beam)]; gy = p.gvec[2 * size_t(beam) + 1]; }
-                    }
+                    for (int k = 1; k < NPASS; ++k) amp = (pass == k) ? amps[k] : amp;   // (a select chain: no dynamic register index)
                     T uadd[3], a[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) uadd[c] = uin[c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp;
+                    for (int c = 0; c < 3; ++c) uadd[c] = cur.uin[c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp;
                     // (beams past the ensemble's end run on zeros: finite, never stored into the state)
-                    loop_rhs<T, LV, LOGNW, GRAV, EM>(tab, my_kind, gx, gy, corrected, drag_on, lds3, tl, lane, j, S, slot_ok, sq, sv, uadd, a);
+                    loop_rhs<T, LV, LOGNW, GRAV, EM>(tab, my_kind, cur.gx, cur.gy, corrected, drag_on, lds3, tl, lane, j, S, slot_ok, cur.sq, cur.sv, uadd, a);
+                    // ---- RK4 bookkeeping of this pass
+                    const unsigned ab = acc_base + unsigned(pass * 256 * sizeof(T));
+                    auto acc_at = [&](int c) -> T& { return *reinterpret_cast<T*>(crb_smem + ab + unsigned(c * NLI * sizeof(T))); };
                     T nq[3], nv[3], oq[3], ov[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        nq[c] = aq[c] + w * sv[c];
-                        nv[c] = av[c] + w * a[c];
-                        oq[c] = (s < 3) ? x0q[c] + cs * sv[c] : x0q[c] + dt6 * nq[c];
-                        ov[c] = (s < 3) ? x0v[c] + cs * a[c] : x0v[c] + dt6 * nv[c];
+                        const T aq = s ? acc_at(c) : T(0), av = s ? acc_at(3 + c) : T(0);
+                        nq[c] = aq + w * cur.sv[c];
+                        nv[c] = av + w * a[c];
+                        oq[c] = (s < 3) ? cur.x0q[c] + cs * cur.sv[c] : cur.x0q[c] + dt6 * nq[c];
+                        ov[c] = (s < 3) ? cur.x0v[c] + cs * a[c] : cur.x0v[c] + dt6 * nv[c];
                     }
+                    t2* o = own_at(own, pass);
                     if (s < 3) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) { accs[size_t(c) * NLI + li] = nq[c]; accs[size_t(3 + c) * NLI + li] = nv[c]; }
+                        for (int c = 0; c < 3; ++c) { acc_at(c) = nq[c]; acc_at(3 + c) = nv[c]; }
                     } else if (!last_step) {
-                        x0p[0] = t2{oq[0], oq[1]}; x0p[1] = t2{oq[2], ov[0]}; x0p[2] = t2{ov[1], ov[2]};
+                        o[0] = t2{oq[0], oq[1]}; o[1] = t2{oq[2], ov[0]}; o[2] = t2{ov[1], ov[2]};
                     } else if (slot_ok && beam < p.B) {   // the rollout's last stage: the state back into the device layout
                         typedef T rec4 __attribute__((ext_vector_type(4)));
                         T* dst = p.x + size_t(beam) * 2 * plane + size_t(j + p.off) * 4;
                         *reinterpret_cast<rec4*>(dst) = rec4{oq[0], oq[1], oq[2], T(0)};
                         *reinterpret_cast<rec4*>(dst + plane) = rec4{ov[0], ov[1], ov[2], T(0)};
                     }
-                    if (s == 3 && last_step) continue;   // (nobody reads a stage state after the rollout's last stage)
-                    if (HAS_REF) {
-                        T eq[3] = {T(0), T(0), T(0)}, ev[3] = {T(0), T(0), T(0)};
-                        if (beam < p.B) {
+                    if (!(s == 3 && last_step)) {   // (nobody reads a stage state after the rollout's last stage)
+                        o[3] = t2{oq[0], oq[1]}; o[4] = t2{oq[2], ov[0]}; o[5] = t2{ov[1], ov[2]};
+                        const unsigned eo = e_base + unsigned(pass * BPP * 12 * sizeof(T));
+                        if (HAS_REF) {
+                            T eq[3], ev[3];
 #pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                if (red[c] >= 0) {
-                                    eq[c] = P.ref[size_t(beam) * 2 * P.n_red + red[c]] - oq[c];
-                                    ev[c] = P.ref[size_t(beam) * 2 * P.n_red + P.n_red + red[c]] - ov[c];
-                                }
+                            for (int c = 0; c < 3; ++c) { eq[c] = red[c] >= 0 ? cur_ref.rq[c] - oq[c] : T(0); ev[c] = red[c] >= 0 ? cur_ref.rv[c] - ov[c] : T(0); }
+                            loop_st6(ers, eo, eq, ev);
+                        } else {
+                            loop_st6(ers, eo, oq, ov);
                         }
-                        loop_st6(ers, e_off(bl), eq, ev);
-                        loop_st6(xrs, e_off(bl), oq, ov);
-                    } else {
-                        loop_st6(ers, e_off(bl), oq, ov);
                     }
+                    cur = nxt;
+                    if (HAS_REF) cur_ref = nxt_ref;
                 }
+                CRB_LOOP_STAMP(3);
                 // (the rollout's last stage hands nothing on: the next row block's first hand-off orders the rest)
                 if (!(s == 3 && last_step)) {
                     if (!handoff()) return;
                 }
+                CRB_LOOP_STAMP(4);
             }
             tc = t_full;
         }
-        if (p.n_steps == 0) continue;
     }
+#if CRB_LOOP_PROF
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(P.sync + 2) + k, prof[k]);
+    }
+#endif
+#undef CRB_LOOP_STAMP
 }
 
 }  // namespace crb

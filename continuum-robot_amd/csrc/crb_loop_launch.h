@@ -12,20 +12,19 @@ namespace crb {
 hipError_t launch_loop_long(const LoopParams<double>& P, const double* gain, int levels, bool grav, int elem_mode, hipStream_t st);
 hipError_t launch_loop_short(const LoopParams<double>& P, const double* gain, int levels, bool grav, int elem_mode, hipStream_t st);
 
-// Layout of the work buffer (bytes from its start): [sync words][gain fragments][E][Xn][U][x0], every part sized for
+// Layout of the work buffer (bytes from its start): [sync words][gain fragments][E][U][own], every part sized for
 // `groups` groups of NB workgroups (NB = 8 for beams of more than 64 thread-carried nodes, else 4)
 struct LoopWork {
-    size_t kfrag, ebuf, xnbuf, ubuf, x0buf, total;
+    size_t kfrag, ebuf, ubuf, ownbuf, total;
 };
 inline LoopWork loop_work_layout(int nb, int groups) {
     LoopWork w;
-    const size_t e = size_t(8 * nb) * 64 * 12 * sizeof(double), u = size_t(64) * 48 * nb * sizeof(double), x0 = size_t(64) * 16 * nb * 6 * sizeof(double);
+    const size_t e = size_t(8 * nb) * 64 * 12 * sizeof(double), u = size_t(64) * 48 * nb * sizeof(double), own = size_t(64) * 16 * nb * 12 * sizeof(double);
     w.kfrag = size_t(LOOP_SYNC_WORDS) * sizeof(unsigned);
     w.ebuf = w.kfrag + size_t(nb) * 4 * 3 * 6 * nb * 64 * sizeof(double);
-    w.xnbuf = w.ebuf + e * groups;
-    w.ubuf = w.xnbuf + e * groups;
-    w.x0buf = w.ubuf + u * groups;
-    w.total = w.x0buf + x0 * groups;
+    w.ubuf = w.ebuf + e * groups;
+    w.ownbuf = w.ubuf + u * groups;
+    w.total = w.ownbuf + own * groups;
     return w;
 }
 }  // namespace crb

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -88,6 +89,8 @@ struct crb_plan {
     mutable double* d_stage = nullptr;   // the device's view of h_stage
     mutable unsigned long long host_seq = 0;   // sequence number of the last flagged host-path launch
     mutable hipStream_t host_stream = nullptr;
+    double host_spin_ms = 200.0;      // CRB_HOST_SPIN_MS at plan creation: how long a host-path call spins on the completion flag
+    bool host_sync = false;           // CRB_HOST_SYNC at plan creation: wait for the stream instead of the flag
     int32_t* d_n_state = nullptr;     // [B] 2 * n_free_b, or null
     std::vector<double> h_levels, h_final, h_norms, h_mass, h_stiff;
     int first_nonlinear = -1;
@@ -455,6 +458,8 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
 
     crb_plan* p = new crb_plan();
     p->device = device;
+    if (const char* env = std::getenv("CRB_HOST_SPIN_MS")) p->host_spin_ms = std::atof(env);
+    p->host_sync = std::getenv("CRB_HOST_SYNC") != nullptr;
     p->dtype = dtype;
     p->B = n_beams;
     p->n_elem = ne;
@@ -496,7 +501,11 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
         if (topo[b]->n_free > p->n_free) p->n_free = topo[b]->n_free;
         for (size_t f = 0; f < p->any_free.size(); ++f) p->any_free[f] = p->any_free[f] | topo[b]->free_dof[f];
     }
-    if (p->mixed_topology) {
+    // per-beam sizes whenever they differ -- also when the free-DOF sets agree (a longer beam whose extra nodes are all FIXED
+    // has the shorter beam's masks: its element count, and with it the tip node, is still its own)
+    bool sizes_differ = p->mixed_topology;
+    for (int b = 1; b < nd; ++b) sizes_differ = sizes_differ || topo[b]->n_elem != t0.n_elem;
+    if (sizes_differ) {
         p->beam_n_elem.resize(nd); p->beam_n_free.resize(nd); p->beam_free_index.resize(nd);
         for (int b = 0; b < nd; ++b) {
             p->beam_n_elem[b] = topo[b]->n_elem; p->beam_n_free[b] = topo[b]->n_free; p->beam_free_index[b] = topo[b]->free_index;
@@ -715,15 +724,16 @@ extern "C" int crb_plan_get_free_index(const crb_plan* p, int32_t* out) {
 extern "C" int crb_plan_get_beam_info(const crb_plan* p, int beam, int32_t* n_elem, int32_t* n_free) {
     if (!p) return fail(CRB_EINVAL, "null argument");
     if (beam < 0 || beam >= p->B) return fail(CRB_EINVAL, "crb_plan_get_beam_info: beam out of range");
-    if (n_elem) *n_elem = p->mixed_topology ? p->beam_n_elem[beam] : p->n_elem;
-    if (n_free) *n_free = p->mixed_topology ? p->beam_n_free[beam] : int32_t(p->free_index.size());
+    const bool per_beam = !p->beam_n_elem.empty();
+    if (n_elem) *n_elem = per_beam ? p->beam_n_elem[beam] : p->n_elem;
+    if (n_free) *n_free = per_beam ? p->beam_n_free[beam] : int32_t(p->free_index.size());
     return CRB_OK;
 }
 
 extern "C" int crb_plan_get_beam_free_index(const crb_plan* p, int beam, int32_t* out) {
     if (!p || !out) return fail(CRB_EINVAL, "null argument");
     if (beam < 0 || beam >= p->B) return fail(CRB_EINVAL, "crb_plan_get_beam_free_index: beam out of range");
-    const std::vector<int32_t>& fi = p->mixed_topology ? p->beam_free_index[beam] : p->free_index;
+    const std::vector<int32_t>& fi = !p->beam_free_index.empty() ? p->beam_free_index[beam] : p->free_index;
     std::memcpy(out, fi.data(), fi.size() * sizeof(int32_t));
     return CRB_OK;
 }
@@ -1111,15 +1121,26 @@ int host_path_setup(const crb_plan* p, const char* who) {
 
 namespace {
 // Waits for a host-path launch.  One workgroup: the kernel raises a flag in host-mapped memory after its output stores
-// and the host spins on it (a stream synchronise costs ~8 us of wake-up latency on top of a 5 us kernel); anything else,
-// or a flag that does not come within ~200 ms (a failed launch), falls back to the stream.
+// and the host spins on it (a stream synchronise costs ~8 us of wake-up latency on top of a 5 us kernel).  The spin is
+// bounded by the wall clock (CRB_HOST_SPIN_MS, default 200 ms) and looks at the stream every 4096 polls: a launch that failed
+// ends the wait with its error at once, a flag that never comes falls back to synchronising the stream.
 int host_path_wait(const crb_plan* p, bool flagged, unsigned long long seq) {
     if (flagged) {
         const size_t n = p->free_index.size();
         volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(p->h_stage + size_t(p->B) * 5 * n);
-        for (long spin = 0; spin < 200000000L; ++spin) {
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned long spin = 1;; ++spin) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return CRB_OK;
             __builtin_ia32_pause();
+            if ((spin & 4095ul) == 0) {
+                const hipError_t q = hipStreamQuery(p->host_stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(CRB_EHIP, std::string("host-path launch: ") + hipGetErrorString(q));
+                if (q == hipSuccess) break;   // the stream is idle: the kernel has run (its flag store is visible after the synchronise below)
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000.0 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > p->host_spin_ms) break;
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(p->host_stream));
@@ -1140,7 +1161,7 @@ extern "C" int crb_rhs_host(const crb_plan* p, const double* x_red, const double
     k.out = p->d_stage + B * 3 * n;
     k.red_map = p->d_red_map;
     k.n_red = int(n);
-    const bool flagged = (p->B + p->G - 1) / p->G == 1 && std::getenv("CRB_HOST_SYNC") == nullptr;
+    const bool flagged = (p->B + p->G - 1) / p->G == 1 && !p->host_sync;
     if (flagged) {
         k.done_flag = reinterpret_cast<unsigned long long*>(p->d_stage + B * 5 * n);
         k.done_seq = ++p->host_seq;
@@ -1162,7 +1183,7 @@ extern "C" int crb_internal_force_host(const crb_plan* p, const double* q_red, d
     k.out = p->d_stage + B * 3 * n;
     k.red_map = p->d_red_map;
     k.n_red = int(n);
-    const bool flagged = (p->B + p->G - 1) / p->G == 1 && std::getenv("CRB_HOST_SYNC") == nullptr;
+    const bool flagged = (p->B + p->G - 1) / p->G == 1 && !p->host_sync;
     if (flagged) {
         k.done_flag = reinterpret_cast<unsigned long long*>(p->d_stage + B * 5 * n);
         k.done_seq = ++p->host_seq;
@@ -1192,10 +1213,20 @@ int stiff_tables(const crb_plan* p, double alpha, hipStream_t st) {
         for (auto& c : p->stiff_sets)
             if (c.used < set->used) set = &c;
     }
-    if (!set->lev) {
-        HIP_TRY(hipMalloc(&set->lev, size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)));
-        HIP_TRY(hipMalloc(&set->fin, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)));
-        if (!in.dNormScratch.p && in.dNormScratch.alloc(size_t(lf > 0 ? lf : 1))) return fail(CRB_EHIP, "crb_step_implicit: device allocation failed");
+    if (!set->lev || !set->fin) {
+        // both tables or neither: a set with one of them would pass for built at the next call
+        void *lev = nullptr, *fin = nullptr;
+        const bool ok = hipMalloc(&lev, size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS * sizeof(T)) == hipSuccess &&
+                        hipMalloc(&fin, size_t(nd) * S * PCR_FINAL_VALS * sizeof(T)) == hipSuccess &&
+                        (in.dNormScratch.p || in.dNormScratch.alloc(size_t(lf > 0 ? lf : 1)) == 0);
+        if (!ok) {
+            if (lev) (void)hipFree(lev);
+            if (fin) (void)hipFree(fin);
+            (void)hipGetLastError();
+            return fail(CRB_EHIP, "crb_step_implicit: device allocation failed");
+        }
+        set->lev = lev;
+        set->fin = fin;
     }
     set->used = ++p->stiff_clock;
     p->d_alevels = set->lev;
@@ -1535,9 +1566,8 @@ extern "C" int crb_step_rk4_feedback(const crb_plan* p, void* x, double t0, doub
         P.sync = reinterpret_cast<unsigned*>(w);
         P.kfrag = reinterpret_cast<const double*>(w + lay.kfrag);
         P.ebuf = reinterpret_cast<double*>(w + lay.ebuf);
-        P.xnbuf = reinterpret_cast<double*>(w + lay.xnbuf);
         P.ubuf = reinterpret_cast<double*>(w + lay.ubuf);
-        P.x0buf = reinterpret_cast<double*>(w + lay.x0buf);
+        P.ownbuf = reinterpret_cast<double*>(w + lay.ownbuf);
         P.n_rb = n_rb;
         const char* fenv = std::getenv("CRB_LOOP_FENCES");
         P.fences = fenv ? std::atoi(fenv) : 0;

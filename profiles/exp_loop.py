@@ -84,8 +84,30 @@ def timeit(n_e=128, B=2048, steps=100, reps=5):
     return out
 
 
+def prof(n_e=128, B=2048, steps=50):
+    """phase breakdown of a CRB_LOOP_PROF=1 build (make fast EXTRA=-DCRB_LOOP_PROF=1, CRB_LIB_PATH=..._fast.so)"""
+    os.environ["CRB_LOOP"] = "1"
+    rng = np.random.default_rng(7)
+    ens = ens_of(n_e, B)
+    n = ens.n
+    gain = rng.normal(0.0, 2e-2, (n, 2 * n))
+    ens.set_state(rng.normal(0.0, 1e-5, (B, 2 * n)))
+    for _ in range(2):
+        ens.step_feedback(steps, 5e-6, gain, impulse_amp=np.ones(B))
+        torch.cuda.synchronize()
+    words = ens._feedback_work[:128].cpu().numpy().view(np.uint64)
+    tot = words[1:11].astype(np.float64)
+    nwg = ((B + 63) // 64) * (8 if n_e > 64 else 4)
+    per_stage = tot / nwg / (4 * steps) * 0.01   # us (100 MHz ticks)
+    names = ["gemm", "reduce+store U", "hand-off A", "bookkeeping+stores", "hand-off B", "loop overhead", "rhs x passes", "-", "-", "-"]
+    print("prof per stage (us): " + ", ".join(f"{k} {v:.2f}" for k, v in zip(names, per_stage)) + f"; sum {per_stage.sum():.2f}", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "check"
+    if what == "prof":
+        prof()
+        sys.exit(0)
     ok = True
     if what in ("check", "all"):
         ok &= check(128, 70, 12)

@@ -88,22 +88,35 @@ def block_errs(got, ref, free_index, floor=BLOCK_FLOOR):
     return out
 
 
-def assert_blocks(got, ref, free_index, tol, bar=1e-6, what="", cond=None, cond_factor=16.0):
+AXIAL_BLOCKS = ("u", "du_dt")
+COND_MIN_STEPS = 600      # below this horizon every block of every golden rollout keeps its fixed bound (measured <= 2e-15)
+COND_CEILING = 1e-4       # no conditioning argument admits more than this; beyond it parity is unpinned, not met
+ADMITTED = []             # (what, block, error, allowed) of every block that passed through the conditioning clause
+
+
+def assert_blocks(got, ref, free_index, tol, bar=1e-6, what="", cond=None, cond_factor=16.0, steps=None):
     """Every DOF block within ``tol`` (the measured bound, written at the call site; never looser than
     north_star's 1e-6 ``bar``).  Returns the per-block errors.
 
-    ``cond`` (from ``rollout_conditioning``): per-block forward error of the ORACLE ITSELF under a 4-ulp
-    relative perturbation of its input.  Where the trajectory is ill-conditioned -- the shipped f1 of the
-    reference (segments.py:178-208) makes the axial DOFs of long nonlinear chains
-    exponentially unstable, rounding differences grow x1000 per 200 steps beyond step 600, and the C oracle
-    itself is 3.4e-6 away from the reference's own du/dt block at 1000 steps (nl256_drag, tests/golden) -- no
-    implementation that rounds differently can meet a fixed bound, and the block is held to
-    ``cond_factor`` x that sensitivity instead (i.e. to the oracle's own response to a 64-ulp input change)."""
+    ``cond`` (from ``rollout_conditioning``) + ``steps``: the conditioning clause, for the AXIAL blocks (u, du/dt) of
+    rollouts longer than COND_MIN_STEPS steps ONLY.  ``cond`` is the per-block forward error of the ORACLE ITSELF under
+    a 4-ulp relative perturbation of its input.  The shipped f1 of the reference (segments.py:178-208)
+    makes the axial DOFs of long nonlinear chains exponentially unstable: rounding differences grow x1000 per 200 steps
+    beyond step 600, and the C oracle itself is 3.4e-6 away from the reference's own du/dt block at 1000 steps
+    (nl256_drag, tests/golden) -- no implementation that rounds differently can meet a fixed bound there.  Such a block
+    is held to ``cond_factor`` x that sensitivity (the oracle's own response to a 64-ulp input change), capped at
+    COND_CEILING, and is recorded in ADMITTED.  w, phi and their rates never take this clause, whatever is passed."""
     errs = block_errs(got, ref, free_index)
     assert tol <= bar * (1 + 1e-12)
     for k, e in errs.items():
-        allowed = max(tol, cond_factor * cond.get(k, 0.0)) if cond else tol
+        allowed = tol
+        if cond and k in AXIAL_BLOCKS and steps is not None and steps > COND_MIN_STEPS:
+            allowed = min(max(tol, cond_factor * cond.get(k, 0.0)), COND_CEILING)
         assert e <= allowed, (what, k, e, allowed, errs, cond)
+        if e > tol:
+            ADMITTED.append((what, k, e, allowed))
+            print(f"[assert_blocks] {what}: block {k} admitted through the conditioning clause: {e:.2e} <= {allowed:.2e} "
+                  f"(fixed bound {tol:.0e}; parity of this block is unpinned at this horizon)")
     return errs
 
 

@@ -100,10 +100,15 @@ def test_rk4_rollouts_match_reference(golden, name):
         # long nonlinear chains beyond ~600 steps are ill-conditioned (shipped f1; helpers.assert_blocks) and are
         # held to the oracle's own sensitivity there
         cond = None
-        if name.startswith("nl"):
+        if name.startswith("nl") and done > 600:
             ob = oracle_beam(beam_columns(z, name), **force_kwargs(z, name))
             cond = rollout_conditioning(ob, z[f"{name}/x0"], dt, done, amp, duration=dur)
-        assert_blocks(got[0], ref, ens.free_index, 1e-9, what=(name, c), cond=cond)
+        errs = assert_blocks(got[0], ref, ens.free_index, 1e-9, what=(name, c), cond=cond, steps=done)
+        if name == "nl256_drag" and done == 1000:
+            # the metric's horizon against the REFERENCE's own output, numbers at the call site (measured round 2: u 8e-9,
+            # du/dt 6e-6 -- the C oracle itself is 3.4e-6 from this golden there; w 5e-15, phi 2e-14, dw/dt 7e-13, dphi/dt 6e-12)
+            for k, bound in (("w", 1e-12), ("phi", 1e-12), ("dw_dt", 1e-10), ("dphi_dt", 1e-10), ("u", 1e-6), ("du_dt", 5e-5)):
+                assert errs[k] <= bound, (k, errs[k], bound)
         assert abs(got[0, n - 2] - ref[n - 2]) <= 1e-11 * abs(ref[n - 2])  # tip displacement
         assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
 
@@ -369,7 +374,7 @@ def test_full_size_config3_properties():
             # blocks are ill-conditioned there (shipped f1: helpers.assert_blocks) and are held to the oracle's own
             # sensitivity to a 64-ulp change of the impulse amplitude
             cond = rollout_conditioning(ob, np.zeros(2 * ob.n), dt, horizon, amps[b]) if horizon > 600 else None
-            assert_blocks(x[b].cpu().numpy(), ref, ens.free_index, 1e-10, what=(horizon, b), cond=cond)
+            assert_blocks(x[b].cpu().numpy(), ref, ens.free_index, 1e-10, what=(horizon, b), cond=cond, steps=horizon)
             assert abs(tips[b] - ref[ob.n - 2]) <= 1e-11 * abs(ref[ob.n - 2])
 
 

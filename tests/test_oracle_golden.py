@@ -115,8 +115,8 @@ def test_g5_rk4_rollouts(golden, name):
         # (measured <= 3.3e-12 in every block of every rollout) EXCEPT in the axial blocks of the long nonlinear
         # chains beyond ~600 steps, which the shipped f1 makes exponentially unstable (helpers.assert_blocks):
         # there the bound is the oracle's own sensitivity to a 64-ulp change of the impulse amplitude
-        cond = rollout_conditioning(ob, z[f"{name}/x0"], dt, done, amp, duration=dur) if name.startswith("nl") else None
-        assert_blocks(x, ref, ob.red2full(), 1e-11, what=(name, c), cond=cond)
+        cond = rollout_conditioning(ob, z[f"{name}/x0"], dt, done, amp, duration=dur) if name.startswith("nl") and done > 600 else None
+        assert_blocks(x, ref, ob.red2full(), 1e-11, what=(name, c), cond=cond, steps=done)
         assert abs(x[ob.n - 2] - ref[ob.n - 2]) <= 1e-12 * abs(ref[ob.n - 2])
 
 
