@@ -57,9 +57,9 @@ struct LoopParams {
     const T* ref;              // [B][2n] reduced, or nullptr (= regulation to 0)
     const int32_t* red_map;    // [3 n_node]: reduced index of a full DOF or -1 (reference vectors, HAS_REF)
     int n_red;                 // n
-    T* ebuf;                   // [groups][SP][64][12]  stage state (HAS_REF: r - state) in fragment order: the GEMM's A operand
-    T* ubuf;                   // [groups][64][48 NB]   feedback force per beam and padded slot DOF
-    T* ownbuf;                 // [groups][64][16 NB][12] {step-start state, stage state} of every node, private to the workgroup
+    T* ebuf;                   // [groups][64 beams][16 NB slots][q, v]  stage state (HAS_REF: r - state): the GEMM's A operand
+    T* ubuf;                   // [groups][NB][64 beams][48]  feedback force, one contiguous tile per workgroup (column block)
+    T* ownbuf;                 // [groups][NB][passes][6 items][256 threads][16 B] {step-start state, stage state} of every node, private to the workgroup
                                // that owns the beam (plain accesses through L2; what is handed on goes to ebuf write-through)
     unsigned* sync;            // LOOP_SYNC_WORDS words, zeroed before the launch
     int n_rb, n_groups;        // row blocks of 64 beams; groups of NB workgroups in the grid
@@ -74,6 +74,10 @@ __host__ __device__ constexpr size_t loop_ubuf_elems() { return size_t(64) * 48 
 // per-slot table record in LDS, in 16-byte items: [LV levels x 10 multipliers][final 5, drag][element c0..c5][half masses own, left]
 template <int LV>
 __host__ __device__ constexpr int loop_tab_items() { return (LV * 10 + 14) / 2; }
+// beams a thread of the stage phase carries at once (loop_rhs): two where the exchange regions of four beams in flight
+// still fit the CU's 160 KB of LDS next to accumulator, tables and sync words (LV = 5), else one
+template <int LV, int LOGNW>
+__host__ __device__ constexpr int loop_nbi() { return (LOGNW == 0 || LV <= 5) ? 2 : 1; }
 template <typename T, int LV, int LOGNW, int NB>
 __host__ __device__ constexpr size_t loop_lds_bytes() {
     constexpr int NTB = 64 << LOGNW, BPW = 64 / NB, BPP = 256 / NTB;
@@ -82,7 +86,10 @@ __host__ __device__ constexpr size_t loop_lds_bytes() {
     const size_t acc = size_t(6) * BPW * NTB * sizeof(T);
     const size_t tab = size_t(loop_tab_items<LV>()) * NTB * 2 * sizeof(T) + size_t(NTB) * sizeof(int32_t);
     const size_t red = size_t(6) * 3 * 4 * 64 * sizeof(T);
-    const size_t xch = size_t(BPP) * 11 * (NTB + 1) * sizeof(T);
+    // exchange columns of the beams in flight: q (3), then round A (8) -- over which a round's outgoing records are gathered
+    const size_t xch_a = LOGNW == 0 ? 0 : size_t(BPP) * loop_nbi<LV, LOGNW>() * 8 * (NTB + 1) * sizeof(T);
+    const size_t stg = size_t(256) * loop_nbi<LV, LOGNW>() * 6 * sizeof(T);
+    const size_t xch = size_t(BPP) * loop_nbi<LV, LOGNW>() * 3 * (NTB + 1) * sizeof(T) + (xch_a > stg ? xch_a : stg);
     return acc + tab + ((red > xch ? red : xch) + 15) / 16 * 16 + 16;
 }
 
@@ -155,37 +162,49 @@ __global__ void crb_loop_gain_kernel(const T* gain, const int32_t* red_map, int 
     out[idx] = (redr >= 0 && redc >= 0) ? gain[size_t(redr) * 2 * n_red + size_t(kq & 1) * n_red + redc] : T(0);
 }
 
-// One RHS  a = Minv (uadd - k(q) + drag + gravity)  for NTB = 64 << LOGNW threads that carry one beam: the exchange
-// structure of lean_rhs (crb_lean.h) plus the plain cantilever's nearest-neighbour gravity, as crb_stage_lean_kernel
-// evaluates it -- with every table value read from LDS where it is used (`tab`: this thread's record, 16-byte item k
-// at tab[2 k NTB]) instead of living in registers.  `lds3` is this beam's own exchange region, `tl` the thread's index
-// inside the beam.  Barriers are workgroup-wide: every beam of the workgroup runs through here in lockstep.
-template <typename T, int LV, int LOGNW, bool GRAV, int EM>
-__device__ __forceinline__ void loop_rhs(const T* tab, int kind, T gx, T gy, bool corrected, bool drag_on, T* lds3, int tl, int lane,
-                                         int j, int S, bool valid, const T sq[3], const T sv[3], const T uadd[3], T a[3]) {
+// NBI right-hand sides  a = Minv (uadd - k(q) + drag + gravity)  at once: the NTB = 64 << LOGNW threads that carry a
+// beam each evaluate the same node of NBI beams (`lds_q` / `lds_a`: their exchange columns, beam after beam; `tl`: the thread's
+// index inside the beam).  The exchange structure is lean_rhs's (crb_lean.h) plus the plain cantilever's nearest-neighbour gravity, as
+// crb_stage_lean_kernel evaluates it -- with every table value read from LDS where it is used (`tab`: this thread's record,
+// 16-byte item k at tab[2 k NTB]) instead of living in registers.  Why several beams per thread: the workgroup runs ONE wave
+// per SIMD (the register file belongs to the gain), so nothing hides an instruction's latency but independent work of the
+// same wave; the beams share every table read and every barrier.  Barriers are workgroup-wide: all beams of the workgroup
+// run through here in lockstep.
+template <typename T, int LV, int LOGNW, bool GRAV, int EM, int NBI>
+__device__ __forceinline__ void loop_rhs(const T* tab, int kind, const T gx[NBI], const T gy[NBI], bool corrected, bool drag_on, T* lds_q, T* lds_a,
+                                         int tl, int lane, int j, int S, bool valid, const T sq[NBI][3], const T sv[NBI][3],
+                                         const T uadd[NBI][3], T a[NBI][3]) {
     static_assert(LOGNW <= 1, "levels above 0 are lane shifts");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
     typedef T t2 __attribute__((ext_vector_type(2)));
     auto item = [&](int k) { return *reinterpret_cast<const t2*>(tab + size_t(2 * k) * NT); };
-    T* const ldsQ = lds3;                           // [3][NT+1]  stage positions
-    T* const ldsA = lds3 + 3 * size_t(NT + 1);      // [8][NT+1]  p0..2, fl0..2, g0..1
+    auto ldsQ = [&](int i) { return lds_q + size_t(i) * 3 * (NT + 1); };     // [3][NT+1]  stage positions of beam i
+    auto ldsA = [&](int i) { return lds_a + size_t(i) * 8 * (NT + 1); };     // [8][NT+1]  p0..2, fl0..2, g0..1
     auto thread_of = [](int jj) { return ((jj & (NW - 1)) << 6) | (jj >> LOGNW); };
     const bool has_left = valid && j >= 1, has_right = valid && j + 1 < S;
     const int t_l1 = has_left ? thread_of(j - 1) : NULLT;
     const int t_r1 = has_right ? thread_of(j + 1) : NULLT;
     const int t_r2 = (valid && j + 2 < S) ? thread_of(j + 2) : NULLT;
-    T qL[3], phiR = T(0);
+    T qL[NBI][3], phiR[NBI];
     if (LOGNW == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(sq[c], lane);
-        if (GRAV) phiR = lane_higher<T, 1>(sq[2], lane);
+        for (int i = 0; i < NBI; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) qL[i][c] = lane_lower<T, 1>(sq[i][c], lane);
+            phiR[i] = GRAV ? lane_higher<T, 1>(sq[i][2], lane) : T(0);
+        }
     } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) ldsQ[size_t(c) * (NT + 1) + tl] = sq[c];
+        for (int i = 0; i < NBI; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ldsQ(i)[size_t(c) * (NT + 1) + tl] = sq[i][c];
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qL[c] = ldsQ[size_t(c) * (NT + 1) + t_l1];
-        if (GRAV) phiR = ldsQ[size_t(2) * (NT + 1) + t_r1];
+        for (int i = 0; i < NBI; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) qL[i][c] = ldsQ(i)[size_t(c) * (NT + 1) + t_l1];
+            phiR[i] = GRAV ? ldsQ(i)[size_t(2) * (NT + 1) + t_r1] : T(0);
+        }
     }
     ElemCoef<T> ec;
     {
@@ -193,81 +212,106 @@ __device__ __forceinline__ void loop_rhs(const T* tab, int kind, T gx, T gy, boo
         ec.c[0] = c01[0]; ec.c[1] = c01[1]; ec.c[2] = c23[0]; ec.c[3] = c23[1]; ec.c[4] = c45[0]; ec.c[5] = c45[1];
         ec.kind = kind;
     }
-    T fl[3], fr[3];
-    if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
-    else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
-    else elem_force<T>(ec, qL, sq, corrected, fl, fr);
-    T pp[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) pp[c] = uadd[c] - fr[c];
     const t2 f4d = item(5 * LV + 2);   // [final 4, drag]
-    pp[1] += drag_force<T>(drag_on ? f4d[1] : T(0), sv[1]);
+    T fl[NBI][3], pp[NBI][3], g_own[NBI][2];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        T fr[3];
+        if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL[i], sq[i], false, fl[i], fr);
+        else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL[i], sq[i], fl[i], fr);
+        else elem_force<T>(ec, qL[i], sq[i], corrected, fl[i], fr);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pp[i][c] = uadd[i][c] - fr[c];
+        pp[i][1] += drag_force<T>(drag_on ? f4d[1] : T(0), sv[i][1]);
+        g_own[i][0] = g_own[i][1] = T(0);
+    }
     // gravity_forces.py:104-146 on the plain cantilever: segment j averages the rotations of slots j, j+1 and loads slots j
-    // and j+1, so node j carries g(segment j) + g(segment j-1).  One sincos per thread: a thread evaluates ITS segment and
+    // and j+1, so node j carries g(segment j) + g(segment j-1).  One sincos per node: a thread evaluates ITS segment and
     // takes the left one's from the left neighbour (lane shift, or a column of the exchange round below).
-    T g_own[2] = {T(0), T(0)};
     if (GRAV) {
         const t2 hm = item(5 * LV + 6);   // [half mass of segment j, of segment j-1]
-        gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], gx, gy, hm[0], g_own);
-    }
-    T r[3], rlo[3], rhi[3];
-    if (LOGNW == 0) {
-        if (GRAV) {
-            pp[0] += g_own[0] + lane_lower<T, 1>(g_own[0], lane);
-            pp[1] += g_own[1] + lane_lower<T, 1>(g_own[1], lane);
-        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
-            rlo[c] = lane_lower<T, 1>(r[c], lane);
-            rhi[c] = lane_higher<T, 1>(r[c], lane);
+        for (int i = 0; i < NBI; ++i) gravity_segment<T>(has_right ? T(0.5) * (sq[i][2] + phiR[i]) : sq[i][2], gx[i], gy[i], hm[0], g_own[i]);
+    }
+    T r[NBI][3], rlo[NBI][3], rhi[NBI][3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            if (GRAV) {
+                pp[i][0] += g_own[i][0] + lane_lower<T, 1>(g_own[i][0], lane);
+                pp[i][1] += g_own[i][1] + lane_lower<T, 1>(g_own[i][1], lane);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                r[i][c] = pp[i][c] - lane_higher<T, 1>(fl[i][c], lane);
+                rlo[i][c] = lane_lower<T, 1>(r[i][c], lane);
+                rhi[i][c] = lane_higher<T, 1>(r[i][c], lane);
+            }
         }
     } else {
         // round A: {p without gravity, f_left, own segment's gravity}; a node's p is completed from its own and its left
         // neighbour's segment wherever it is needed (this node, and both stride-1 neighbours for level 0)
-        auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
         const int t_l2 = (valid && j >= 2) ? thread_of(j - 2) : NULLT;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { col(c, tl) = pp[c]; col(3 + c, tl) = fl[c]; }
-        if (GRAV) { col(6, tl) = g_own[0]; col(7, tl) = g_own[1]; }
+        for (int i = 0; i < NBI; ++i) {
+            T* A = ldsA(i);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { A[size_t(c) * (NT + 1) + tl] = pp[i][c]; A[size_t(3 + c) * (NT + 1) + tl] = fl[i][c]; }
+            if (GRAV) { A[size_t(6) * (NT + 1) + tl] = g_own[i][0]; A[size_t(7) * (NT + 1) + tl] = g_own[i][1]; }
+            // (the caller gathers outgoing records over these columns between two calls: the "no neighbour" entries are
+            //  zeroed again -- after the barrier above, which every wave passes once it has read what was gathered)
+            if (tl == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) A[size_t(k) * (NT + 1) + NULLT] = T(0);
+            }
+        }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            T p_l = col(c, t_l1), p_o = pp[c], p_r = col(c, t_r1);
-            if (GRAV && c < 2) {
-                const T g_l1 = col(6 + c, t_l1);
-                p_l += g_l1 + col(6 + c, t_l2);
-                p_o += g_own[c] + g_l1;
-                p_r += col(6 + c, t_r1) + g_own[c];
+        for (int i = 0; i < NBI; ++i) {
+            const T* A = ldsA(i);
+            auto col = [&](int k, int th) { return A[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T p_l = col(c, t_l1), p_o = pp[i][c], p_r = col(c, t_r1);
+                if (GRAV && c < 2) {
+                    const T g_l1 = col(6 + c, t_l1);
+                    p_l += g_l1 + col(6 + c, t_l2);
+                    p_o += g_own[i][c] + g_l1;
+                    p_r += col(6 + c, t_r1) + g_own[i][c];
+                }
+                rlo[i][c] = p_l - fl[i][c];
+                r[i][c] = p_o - col(3 + c, t_r1);
+                rhi[i][c] = p_r - col(3 + c, t_r2);
             }
-            rlo[c] = p_l - fl[c];
-            r[c] = p_o - col(3 + c, t_r1);
-            rhi[c] = p_r - col(3 + c, t_r2);
         }
     }
 #pragma unroll
     for (int l = 0; l < LV; ++l) {
-        if (l > 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                switch (l - LOGNW) {
-                    case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
-                    case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
-                    case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
-                    case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
-                    case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
-                    default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
-                }
-            }
-        }
         T cfl[PCR_LEVEL_VALS];
 #pragma unroll
         for (int k = 0; k < 5; ++k) { const t2 v = item(5 * l + k); cfl[2 * k] = v[0]; cfl[2 * k + 1] = v[1]; }
-        pcr_apply_level<T>(cfl, rlo, rhi, r);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            if (l > 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    switch (l - LOGNW) {
+                        case 0: rlo[i][c] = lane_lower<T, 1>(r[i][c], lane); rhi[i][c] = lane_higher<T, 1>(r[i][c], lane); break;
+                        case 1: rlo[i][c] = lane_lower<T, 2>(r[i][c], lane); rhi[i][c] = lane_higher<T, 2>(r[i][c], lane); break;
+                        case 2: rlo[i][c] = lane_lower<T, 4>(r[i][c], lane); rhi[i][c] = lane_higher<T, 4>(r[i][c], lane); break;
+                        case 3: rlo[i][c] = lane_lower<T, 8>(r[i][c], lane); rhi[i][c] = lane_higher<T, 8>(r[i][c], lane); break;
+                        case 4: rlo[i][c] = lane_lower<T, 16>(r[i][c], lane); rhi[i][c] = lane_higher<T, 16>(r[i][c], lane); break;
+                        default: rlo[i][c] = lane_lower<T, 32>(r[i][c], lane); rhi[i][c] = lane_higher<T, 32>(r[i][c], lane); break;
+                    }
+                }
+            }
+            pcr_apply_level<T>(cfl, rlo[i], rhi[i], r[i]);
+        }
     }
     const t2 f01 = item(5 * LV), f23 = item(5 * LV + 1);
     const T fin[5] = {f01[0], f01[1], f23[0], f23[1], f4d[0]};
-    pcr_apply_final<T>(fin, r, a);
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) pcr_apply_final<T>(fin, r[i], a[i]);
 }
 
 // NB workgroups per group (= column blocks of 48 = 16 slots each; slots padded to 16 NB = the threads that carry a beam),
@@ -283,7 +327,8 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     static_assert(SPAD == NTB, "one thread per padded slot");
     static_assert(NPASS * BPP == BPW && BPW * NB == 64, "beams of a row block divide evenly");
     static_assert(D >= 2 && D <= SPW, "pipeline depth");
-    constexpr int XCH = 11 * (NTB + 1);   // exchange doubles per beam in flight: q (3), p (3), f_left (3), segment gravity (2)
+    constexpr int NBI = loop_nbi<LV, LOGNW>(), NDP = NPASS / NBI;   // beams a thread carries at once; such rounds per stage
+    static_assert(NDP * NBI == NPASS, "passes divide into rounds");
     constexpr int ITEMS = loop_tab_items<LV>();
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const accs = reinterpret_cast<T*>(crb_smem);                 // [6][NLI]: RK4 accumulator q, v
@@ -369,7 +414,10 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     const int S = p.S;
     const int j = (lane << LOGNW) | wib;
     const bool slot_ok = j < S;
-    T* const lds3 = scratch + size_t(sub) * XCH;
+    // exchange columns of the beams in flight: [BPP NBI beams][q: 3 columns], then [BPP NBI beams][round A: 8 columns: p, f_left,
+    // segment gravity]; this thread's beams are sub NBI + i
+    T* const lds_q = scratch + size_t(sub) * NBI * 3 * (NTB + 1);
+    T* const lds_a = scratch + size_t(BPP) * NBI * 3 * (NTB + 1) + size_t(sub) * NBI * 8 * (NTB + 1);
     const T* const tab = tabs + size_t(2) * tl;
     const bool corrected = (p.flags & 4u) != 0, drag_on = (p.flags & 1u) != 0;
     const size_t plane = size_t(p.n_node) * 4;
@@ -409,39 +457,28 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
         __builtin_amdgcn_make_buffer_rsrc(P.ebuf + size_t(group) * loop_ebuf_elems<NB>(), 0, unsigned(loop_ebuf_elems<NB>() * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t urs =
         __builtin_amdgcn_make_buffer_rsrc(P.ubuf + size_t(group) * loop_ubuf_elems<NB>(), 0, unsigned(loop_ubuf_elems<NB>() * sizeof(T)), 0x00020000);
-    // this thread's nodes in the private buffer: [pass][256 threads][x0 q, x0 v, xs q, xs v], as a byte offset (< 4 GB) from its
-    // start (an offset, not a pointer, is what gets laundered below: a laundered pointer loses its address space)
-    const unsigned mine = unsigned(((size_t(group) * NB + y) * NLI + t) * 12 * sizeof(T));
-    auto own_at = [&](unsigned off, int pass) { return reinterpret_cast<t2*>(reinterpret_cast<unsigned char*>(P.ownbuf) + off + unsigned(pass * 256 * 12 * sizeof(T))); };
-    // byte offsets: this lane's first A fragment; this thread's stage record / force of beam `bl` of the workgroup
-    const unsigned a_off0 = unsigned((((SPW * wave) * 64 + fi) * 12 + 3 * kq) * sizeof(T));
-    auto e_off = [&](int bl) { return unsigned((((j >> 1) * 64 + (y * BPW + bl)) * 12 + (j & 1) * 6) * sizeof(T)); };
-    auto u_off = [&](int bl) { return unsigned(((y * BPW + bl) * NCOL + 3 * j) * sizeof(T)); };
-    const int kind = 0;   // (set after the tables' barrier below)
-    (void)kind;
+    // this thread's nodes in the private buffer: [pass][item 0..5][256 threads] 16-byte items {x0 q0 q1 | q2 v0 | v1 v2 | xs ...}
+    // (a wave's access to one item is 1 KB contiguous), as a byte offset (< 4 GB) from the buffer's start -- an offset, not a
+    // pointer, is what gets laundered below: a laundered pointer loses its address space
+    const unsigned mine = unsigned((((size_t(group) * NB + y) * NPASS * 6) * 256 + t) * 2 * sizeof(T));
+    auto own_at = [&](unsigned off, int pass, int item) {
+        return reinterpret_cast<t2*>(reinterpret_cast<unsigned char*>(P.ownbuf) + off + unsigned(((pass * 6 + item) * 256) * 2 * sizeof(T)));
+    };
+    // byte offsets: this lane's first A fragment (row fi of a 16-beam tile, slot pair SPW wave, k quarter kq); this thread's
+    // stage record / force of beam `bl` of the workgroup
+    const unsigned a_off0 = unsigned(((fi * SPAD + 2 * SPW * wave) * 6 + 3 * kq) * sizeof(T));
+    auto e_off = [&](int bl) { return unsigned((((y * BPW + bl) * SPAD + j) * 6) * sizeof(T)); };
+    auto u_off = [&](int bl) { return unsigned(((((j >> 4) * 64) + (y * BPW + bl)) * 48 + 3 * (j & 15)) * sizeof(T)); };
 
-    // inputs of one pass of the stage phase: this thread's stage record and step-start record (private buffer), its
-    // feedback force, its beam's gravity vector (and its entries of the reference)
-    struct PassIn { T sq[3], sv[3], x0q[3], x0v[3], uin[3], gx, gy; };
-    struct PassRef { T rq[3], rv[3]; };   // (its own object: copied only where a reference exists)
-    auto load_own = [&](PassIn& in, PassRef& rf, unsigned own, int pass, int rb) {
-        const t2* o = own_at(own, pass);
-        const t2 v0 = o[0], v1 = o[1], v2 = o[2], v3 = o[3], v4 = o[4], v5 = o[5];
-        in.x0q[0] = v0[0]; in.x0q[1] = v0[1]; in.x0q[2] = v1[0]; in.x0v[0] = v1[1]; in.x0v[1] = v2[0]; in.x0v[2] = v2[1];
-        in.sq[0] = v3[0]; in.sq[1] = v3[1]; in.sq[2] = v4[0]; in.sv[0] = v4[1]; in.sv[1] = v5[0]; in.sv[2] = v5[1];
-        in.gx = p.gx; in.gy = p.gy;
-        if ((GRAV && p.gvec) || HAS_REF) {
-            const int beam = rb * 64 + y * BPW + pass * BPP + sub;
-            const bool real = beam < p.B;
-            if (GRAV && p.gvec && real) { in.gx = p.gvec[2 * size_t(beam)]; in.gy = p.gvec[2 * size_t(beam) + 1]; }
-            if (HAS_REF) {
-                const T* rrow = P.ref + size_t(real ? beam : 0) * 2 * P.n_red;
+    // inputs of one round of the stage phase (NBI beams per thread; beam i of round dp is pass dp NBI + i of the buffers):
+    // the stage records (private buffer) and the feedback forces, requested one round ahead
+    struct RoundIn { T sq[NBI][3], sv[NBI][3], uin[NBI][3]; };
+    auto load_round = [&](RoundIn& in, unsigned own, unsigned ub, int dp, bool with_u) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    rf.rq[c] = (red[c] >= 0 && real) ? rrow[red[c]] : T(0);
-                    rf.rv[c] = (red[c] >= 0 && real) ? rrow[P.n_red + red[c]] : T(0);
-                }
-            }
+        for (int i = 0; i < NBI; ++i) {
+            const t2 v3 = *own_at(own, dp * NBI + i, 3), v4 = *own_at(own, dp * NBI + i, 4), v5 = *own_at(own, dp * NBI + i, 5);
+            in.sq[i][0] = v3[0]; in.sq[i][1] = v3[1]; in.sq[i][2] = v4[0]; in.sv[i][0] = v4[1]; in.sv[i][1] = v5[0]; in.sv[i][2] = v5[1];
+            if (with_u) loop_ld3(urs, ub + unsigned((dp * NBI + i) * BPP * 48 * sizeof(T)), in.uin[i]);
         }
     };
 
@@ -457,9 +494,8 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { xq[c] = p.x[xoff + c] * sc.mask[c]; xv[c] = p.x[xoff + plane + c] * sc.mask[c]; }
             }
-            t2* own = own_at(mine, pass);
-            own[0] = t2{xq[0], xq[1]}; own[1] = t2{xq[2], xv[0]}; own[2] = t2{xv[1], xv[2]};
-            own[3] = t2{xq[0], xq[1]}; own[4] = t2{xq[2], xv[0]}; own[5] = t2{xv[1], xv[2]};
+            *own_at(mine, pass, 0) = t2{xq[0], xq[1]}; *own_at(mine, pass, 1) = t2{xq[2], xv[0]}; *own_at(mine, pass, 2) = t2{xv[1], xv[2]};
+            *own_at(mine, pass, 3) = t2{xq[0], xq[1]}; *own_at(mine, pass, 4) = t2{xq[2], xv[0]}; *own_at(mine, pass, 5) = t2{xv[1], xv[2]};
             if (HAS_REF) {
                 T eq[3] = {T(0), T(0), T(0)}, ev[3] = {T(0), T(0), T(0)};
                 if (beam < p.B) {
@@ -510,7 +546,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                     const T* bl = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(P.kfrag) + b_off);
                     auto fetch = [&](int spl) {
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) loop_ld3(ers, a_off0 + unsigned((spl * 64 + 16 * m) * 12 * sizeof(T)), af[spl % D][m]);
+                        for (int m = 0; m < 4; ++m) loop_ld3(ers, a_off0 + unsigned((16 * m * SPAD * 6 + spl * 12) * sizeof(T)), af[spl % D][m]);
                         if (loop_b_streamed<NB>(2, 3 * spl)) {
 #pragma unroll
                             for (int tt = 0; tt < 3; ++tt) bs[spl % D][tt] = bl[size_t(3 * spl + tt) * 64];
@@ -539,12 +575,14 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                                    "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]));
                 }
                 CRB_LOOP_STAMP(0);
-                // ---- split-K: wave w owns row tile m = w; partial tiles change hands through LDS, two owners per round.
+                // ---- split-K: wave w owns row tile m = w; partial tiles change hands through LDS, two owners per round; the
+                // summed tile is then laid out in LDS as it lies in memory ([64 beams][48 columns], contiguous per workgroup)
+                // and leaves in 1 KB pieces per store instruction: a write-through store costs a fabric write per lane unless
+                // the lanes of an instruction fill whole lines.
                 // (addresses are formed from ONE laundered base per use: hoisted out of the step loop, the 100-odd
                 //  distinct addresses of this block would each take a register and end in scratch)
                 unsigned red_base = unsigned(reinterpret_cast<unsigned char*>(scratch) - crb_smem) + unsigned(lane) * unsigned(sizeof(T));
-                unsigned u_base = unsigned((((lane >> 4) + 16 * wave) * NCOL + 48 * y + fi) * sizeof(T));
-                asm volatile("" : "+v"(red_base), "+v"(u_base));
+                asm volatile("" : "+v"(red_base));
 #pragma unroll
                 for (int round = 0; round < 2; ++round) {
 #pragma unroll
@@ -572,20 +610,32 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                                     T sum = acc[m][n][reg];
 #pragma unroll
                                     for (int k = 0; k < 3; ++k) sum += *reinterpret_cast<const T*>(src + (k * 12 + n * 4 + reg) * 64 * sizeof(T));
-                                    // row 16 m + (lane >> 4) + 4 reg, column 48 y + 16 n + fi   (m = wave here)
-                                    const T v = HAS_REF ? sum : -sum;
-                                    __builtin_amdgcn_raw_buffer_store_b64(
-                                        loop_u2{unsigned(__double2loint(v)), unsigned(__double2hiint(v))}, urs,
-                                        u_base + unsigned((4 * reg * NCOL + 16 * n) * sizeof(T)), 0, LOOP_SC1);
+                                    acc[m][n][reg] = HAS_REF ? sum : -sum;
                                 }
                         }
                     }
                     __syncthreads();
                 }
-                // (the exchange columns share the scratch: their "no neighbour" entries are zeroed again)
-                if (LOGNW > 0 && tl == 0) {
+                {
+                    // row 16 wave + (lane >> 4) + 4 reg, column 16 n + fi of the workgroup's tile
+                    unsigned char* tile = reinterpret_cast<unsigned char*>(scratch);
+                    unsigned t_base = unsigned((((lane >> 4) + 16 * wave) * 48 + fi) * sizeof(T)), s_base = unsigned((wave * 64 + lane) * 16);
+                    asm volatile("" : "+v"(t_base), "+v"(s_base));
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) lds3[size_t(k) * (NTB + 1) + NTB] = T(0);
+                    for (int m = 0; m < 4; ++m)
+                        if (wave == m) {
+#pragma unroll
+                            for (int n = 0; n < 3; ++n)
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) *reinterpret_cast<T*>(tile + t_base + (4 * reg * 48 + 16 * n) * sizeof(T)) = acc[m][n][reg];
+                        }
+                    __syncthreads();
+                    const unsigned ug = unsigned(y * 64 * 48 * sizeof(T));
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {   // 24 KB = 24 pieces of 1 KB, six per wave
+                        const loop_u4 v = *reinterpret_cast<const loop_u4*>(tile + s_base + c * 4096);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, urs, ug + s_base + c * 4096, 0, LOOP_SC1);
+                    }
                 }
                 CRB_LOOP_STAMP(1);
                 // ======================================================== stage phase: whole beams
@@ -596,77 +646,136 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                 // spill reloads (the register budget of this phase is why part of the gain slice is streamed), no
                 // loads of per-beam constants.  The workgroup's own records of the first pass are requested while it
                 // waits for the other workgroups' tiles.
-                PassIn cur, nxt;
-                PassRef cur_ref, nxt_ref;
+                RoundIn cur, nxt;
                 // (bases laundered per stage: hoisted out of the step loop, every address below would hold a register)
-                unsigned e_base = e_off(sub), ub = u_off(sub), acc_base = unsigned(reinterpret_cast<unsigned char*>(accs) - crb_smem) + unsigned(t) * unsigned(sizeof(T));
+                unsigned ub = u_off(sub), acc_base = unsigned(reinterpret_cast<unsigned char*>(accs) - crb_smem) + unsigned(t) * unsigned(sizeof(T));
                 unsigned own = mine;
-                asm volatile("" : "+v"(e_base), "+v"(ub), "+v"(acc_base), "+v"(own));
+                asm volatile("" : "+v"(ub), "+v"(acc_base), "+v"(own));
                 arrive();
-                load_own(cur, cur_ref, own, 0, rb);
+                // (the exchange columns share the scratch with the tile just stored -- every wave has read its pieces before the
+                //  barrier inside arrive(): their "no neighbour" entries are zeroed again)
+                if (LOGNW > 0 && tl == 0) {
+#pragma unroll
+                    for (int k = 0; k < 3 * NBI; ++k) lds_q[size_t(k) * (NTB + 1) + NTB] = T(0);
+#pragma unroll
+                    for (int k = 0; k < 8 * NBI; ++k) lds_a[size_t(k) * (NTB + 1) + NTB] = T(0);
+                }
+                load_round(cur, own, ub, 0, false);
                 if (!wait()) return;
-                loop_ld3(urs, ub, cur.uin);
+#pragma unroll
+                for (int i = 0; i < NBI; ++i) loop_ld3(urs, ub + unsigned(i * BPP * 48 * sizeof(T)), cur.uin[i]);
                 CRB_LOOP_STAMP(2);
                 const double ts = (s == 0) ? tc : ((s == 3) ? t_full : t_half);
                 const bool imp_on = ts < p.duration;
                 const T w = (s == 0 || s == 3) ? T(1) : T(2);
                 const T cs = (s == 2) ? dt : hdt;
 #pragma unroll 1
-                for (int pass = 0; pass < NPASS; ++pass) {
-                    const int bl = pass * BPP + sub, beam = rb * 64 + y * BPW + bl;
+                for (int dp = 0; dp < NDP; ++dp) {
                     nxt = cur;
-                    if (HAS_REF) nxt_ref = cur_ref;
-                    if (pass + 1 < NPASS) {
-                        load_own(nxt, nxt_ref, own, pass + 1, rb);
-                        loop_ld3(urs, ub + unsigned((pass + 1) * BPP * NCOL * sizeof(T)), nxt.uin);
+                    if (dp + 1 < NDP) load_round(nxt, own, ub, dp + 1, true);
+                    // the step-start records (needed after the right-hand sides), per-beam constants
+                    T x0q[NBI][3], x0v[NBI][3], gx[NBI], gy[NBI], rq[HAS_REF ? NBI : 1][3], rv[HAS_REF ? NBI : 1][3];
+#pragma unroll
+                    for (int i = 0; i < NBI; ++i) {
+                        const t2 v0 = *own_at(own, dp * NBI + i, 0), v1 = *own_at(own, dp * NBI + i, 1), v2 = *own_at(own, dp * NBI + i, 2);
+                        x0q[i][0] = v0[0]; x0q[i][1] = v0[1]; x0q[i][2] = v1[0]; x0v[i][0] = v1[1]; x0v[i][1] = v2[0]; x0v[i][2] = v2[1];
+                        gx[i] = p.gx; gy[i] = p.gy;
+                        if ((GRAV && p.gvec) || HAS_REF) {
+                            const int beam = rb * 64 + y * BPW + (dp * NBI + i) * BPP + sub;
+                            const bool real = beam < p.B;
+                            if (GRAV && p.gvec && real) { gx[i] = p.gvec[2 * size_t(beam)]; gy[i] = p.gvec[2 * size_t(beam) + 1]; }
+                            if (HAS_REF) {
+                                const T* rrow = P.ref + size_t(real ? beam : 0) * 2 * P.n_red;
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) {
+                                    rq[HAS_REF ? i : 0][c] = (red[c] >= 0 && real) ? rrow[red[c]] : T(0);
+                                    rv[HAS_REF ? i : 0][c] = (red[c] >= 0 && real) ? rrow[P.n_red + red[c]] : T(0);
+                                }
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    T amp = amps[0];
+                    CRB_LOOP_STAMP(6);
+                    T uadd[NBI][3], a[NBI][3];
 #pragma unroll
-                    for (int k = 1; k < NPASS; ++k) amp = (pass == k) ? amps[k] : amp;   // (a select chain: no dynamic register index)
-                    T uadd[3], a[3];
+                    for (int i = 0; i < NBI; ++i) {
+                        T amp = amps[i];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) uadd[c] = cur.uin[c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp;
+                        for (int k = 1; k < NDP; ++k) amp = (dp == k) ? amps[k * NBI + i] : amp;   // (a select chain: no dynamic register index)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) uadd[i][c] = cur.uin[i][c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp;
+                    }
                     // (beams past the ensemble's end run on zeros: finite, never stored into the state)
-                    loop_rhs<T, LV, LOGNW, GRAV, EM>(tab, my_kind, cur.gx, cur.gy, corrected, drag_on, lds3, tl, lane, j, S, slot_ok, cur.sq, cur.sv, uadd, a);
-                    // ---- RK4 bookkeeping of this pass
-                    const unsigned ab = acc_base + unsigned(pass * 256 * sizeof(T));
-                    auto acc_at = [&](int c) -> T& { return *reinterpret_cast<T*>(crb_smem + ab + unsigned(c * NLI * sizeof(T))); };
-                    T nq[3], nv[3], oq[3], ov[3];
+                    loop_rhs<T, LV, LOGNW, GRAV, EM, NBI>(tab, my_kind, gx, gy, corrected, drag_on, lds_q, lds_a, tl, lane, j, S, slot_ok, cur.sq, cur.sv, uadd, a);
+                    CRB_LOOP_STAMP(7);
+                    // ---- RK4 bookkeeping of this round
+                    T eo[NBI][6];   // what the GEMM reads of each beam: the new stage state (with a reference: r - state)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const T aq = s ? acc_at(c) : T(0), av = s ? acc_at(3 + c) : T(0);
-                        nq[c] = aq + w * cur.sv[c];
-                        nv[c] = av + w * a[c];
-                        oq[c] = (s < 3) ? cur.x0q[c] + cs * cur.sv[c] : cur.x0q[c] + dt6 * nq[c];
-                        ov[c] = (s < 3) ? cur.x0v[c] + cs * a[c] : cur.x0v[c] + dt6 * nv[c];
-                    }
-                    t2* o = own_at(own, pass);
-                    if (s < 3) {
+                    for (int i = 0; i < NBI; ++i) {
+                        const int pass = dp * NBI + i;
+                        const int beam = rb * 64 + y * BPW + pass * BPP + sub;
+                        const unsigned ab = acc_base + unsigned(pass * 256 * sizeof(T));
+                        auto acc_at = [&](int c) -> T& { return *reinterpret_cast<T*>(crb_smem + ab + unsigned(c * NLI * sizeof(T))); };
+                        T nq[3], nv[3], oq[3], ov[3];
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) { acc_at(c) = nq[c]; acc_at(3 + c) = nv[c]; }
-                    } else if (!last_step) {
-                        o[0] = t2{oq[0], oq[1]}; o[1] = t2{oq[2], ov[0]}; o[2] = t2{ov[1], ov[2]};
-                    } else if (slot_ok && beam < p.B) {   // the rollout's last stage: the state back into the device layout
-                        typedef T rec4 __attribute__((ext_vector_type(4)));
-                        T* dst = p.x + size_t(beam) * 2 * plane + size_t(j + p.off) * 4;
-                        *reinterpret_cast<rec4*>(dst) = rec4{oq[0], oq[1], oq[2], T(0)};
-                        *reinterpret_cast<rec4*>(dst + plane) = rec4{ov[0], ov[1], ov[2], T(0)};
-                    }
-                    if (!(s == 3 && last_step)) {   // (nobody reads a stage state after the rollout's last stage)
-                        o[3] = t2{oq[0], oq[1]}; o[4] = t2{oq[2], ov[0]}; o[5] = t2{ov[1], ov[2]};
-                        const unsigned eo = e_base + unsigned(pass * BPP * 12 * sizeof(T));
+                        for (int c = 0; c < 3; ++c) {
+                            const T aq = s ? acc_at(c) : T(0), av = s ? acc_at(3 + c) : T(0);
+                            nq[c] = aq + w * cur.sv[i][c];
+                            nv[c] = av + w * a[i][c];
+                            oq[c] = (s < 3) ? x0q[i][c] + cs * cur.sv[i][c] : x0q[i][c] + dt6 * nq[c];
+                            ov[c] = (s < 3) ? x0v[i][c] + cs * a[i][c] : x0v[i][c] + dt6 * nv[c];
+                        }
+                        if (s < 3) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { acc_at(c) = nq[c]; acc_at(3 + c) = nv[c]; }
+                        } else if (!last_step) {
+                            *own_at(own, pass, 0) = t2{oq[0], oq[1]}; *own_at(own, pass, 1) = t2{oq[2], ov[0]}; *own_at(own, pass, 2) = t2{ov[1], ov[2]};
+                        } else if (slot_ok && beam < p.B) {   // the rollout's last stage: the state back into the device layout
+                            typedef T rec4 __attribute__((ext_vector_type(4)));
+                            T* dst = p.x + size_t(beam) * 2 * plane + size_t(j + p.off) * 4;
+                            *reinterpret_cast<rec4*>(dst) = rec4{oq[0], oq[1], oq[2], T(0)};
+                            *reinterpret_cast<rec4*>(dst + plane) = rec4{ov[0], ov[1], ov[2], T(0)};
+                        }
                         if (HAS_REF) {
-                            T eq[3], ev[3];
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) { eq[c] = red[c] >= 0 ? cur_ref.rq[c] - oq[c] : T(0); ev[c] = red[c] >= 0 ? cur_ref.rv[c] - ov[c] : T(0); }
-                            loop_st6(ers, eo, eq, ev);
+                            for (int c = 0; c < 3; ++c) {
+                                eo[i][c] = red[c] >= 0 ? rq[HAS_REF ? i : 0][c] - oq[c] : T(0);
+                                eo[i][3 + c] = red[c] >= 0 ? rv[HAS_REF ? i : 0][c] - ov[c] : T(0);
+                            }
                         } else {
-                            loop_st6(ers, eo, oq, ov);
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) { eo[i][c] = oq[c]; eo[i][3 + c] = ov[c]; }
+                        }
+                        if (!(s == 3 && last_step)) {   // (nobody reads a stage state after the rollout's last stage)
+                            *own_at(own, pass, 3) = t2{oq[0], oq[1]}; *own_at(own, pass, 4) = t2{oq[2], ov[0]}; *own_at(own, pass, 5) = t2{ov[1], ov[2]};
+                        }
+                    }
+                    // ---- what the other workgroups read: the round's records are gathered in LDS as they lie in memory
+                    // ([beam][slot][q, v]: 6 KB contiguous per beam at NB = 8) and leave in 1 KB pieces per store instruction
+                    // (a write-through store costs a fabric write per lane unless the lanes of an instruction fill whole lines:
+                    // 48 bytes per thread straight from the registers took 7 us per stage, a quarter of it in the hand-off)
+                    if (!(s == 3 && last_step)) {
+                        unsigned char* stg = reinterpret_cast<unsigned char*>(scratch + size_t(BPP) * NBI * 3 * (NTB + 1));   // over the round-A columns
+                        __syncthreads();   // (every wave has read its round-A columns)
+#pragma unroll
+                        for (int i = 0; i < NBI; ++i) {
+                            t2* d = reinterpret_cast<t2*>(stg + ((sub * NBI + i) * SPAD + j) * 6 * sizeof(T));
+                            d[0] = t2{eo[i][0], eo[i][1]}; d[1] = t2{eo[i][2], eo[i][3]}; d[2] = t2{eo[i][4], eo[i][5]};
+                        }
+                        __syncthreads();
+                        constexpr int BEAM_BYTES = SPAD * 6 * int(sizeof(T)), PIECES = BPP * NBI * BEAM_BYTES / 1024;
+                        static_assert(BEAM_BYTES % 1024 == 0 && PIECES % 4 == 0, "whole 1 KB pieces, evenly over the waves");
+#pragma unroll
+                        for (int c = 0; c < PIECES / 4; ++c) {
+                            const int piece = c * 4 + wave;                                 // (wave: scalar)
+                            const int r = piece * 1024 / BEAM_BYTES, within = piece * 1024 - r * BEAM_BYTES;   // staged beam r = sub' NBI + i'
+                            const int bl_r = (dp * NBI + r % NBI) * BPP + r / NBI;          // its index among the workgroup's beams
+                            const loop_u4 v = *reinterpret_cast<const loop_u4*>(stg + piece * 1024 + lane * 16);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, ers, unsigned((y * BPW + bl_r) * BEAM_BYTES + within + lane * 16), 0, LOOP_SC1);
                         }
                     }
                     cur = nxt;
-                    if (HAS_REF) cur_ref = nxt_ref;
+                    CRB_LOOP_STAMP(8);
                 }
                 CRB_LOOP_STAMP(3);
                 // (the rollout's last stage hands nothing on: the next row block's first hand-off orders the rest)

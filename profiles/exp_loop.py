@@ -99,7 +99,7 @@ def prof(n_e=128, B=2048, steps=50):
     tot = words[1:11].astype(np.float64)
     nwg = ((B + 63) // 64) * (8 if n_e > 64 else 4)
     per_stage = tot / nwg / (4 * steps) * 0.01   # us (100 MHz ticks)
-    names = ["gemm", "reduce+store U", "hand-off A", "bookkeeping+stores", "hand-off B", "loop overhead", "rhs x passes", "-", "-", "-"]
+    names = ["gemm", "reduce+store U", "hand-off A", "stage(rest)", "hand-off B", "loop overhead", "round: issue", "round: rhs", "round: update+stores", "-"]
     print("prof per stage (us): " + ", ".join(f"{k} {v:.2f}" for k, v in zip(names, per_stage)) + f"; sum {per_stage.sum():.2f}", flush=True)
 
 
