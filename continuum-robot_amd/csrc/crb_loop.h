@@ -57,7 +57,7 @@ struct LoopParams {
     const T* ref;              // [B][2n] reduced, or nullptr (= regulation to 0)
     const int32_t* red_map;    // [3 n_node]: reduced index of a full DOF or -1 (reference vectors, HAS_REF)
     int n_red;                 // n
-    T* ebuf;                   // [groups][64 beams][16 NB slots][q, v]  stage state (HAS_REF: r - state): the GEMM's A operand
+    T* ebuf;                   // [groups][8 NB slot pairs][64 beams][12]  stage state (HAS_REF: r - state) in fragment order: the GEMM's A operand
     T* ubuf;                   // [groups][NB][64 beams][48]  feedback force, one contiguous tile per workgroup (column block)
     T* ownbuf;                 // [groups][NB][passes][6 items][256 threads][16 B] {step-start state, stage state} of every node, private to the workgroup
                                // that owns the beam (plain accesses through L2; what is handed on goes to ebuf write-through)
@@ -466,8 +466,8 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     };
     // byte offsets: this lane's first A fragment (row fi of a 16-beam tile, slot pair SPW wave, k quarter kq); this thread's
     // stage record / force of beam `bl` of the workgroup
-    const unsigned a_off0 = unsigned(((fi * SPAD + 2 * SPW * wave) * 6 + 3 * kq) * sizeof(T));
-    auto e_off = [&](int bl) { return unsigned((((y * BPW + bl) * SPAD + j) * 6) * sizeof(T)); };
+    const unsigned a_off0 = unsigned((((SPW * wave) * 64 + fi) * 12 + 3 * kq) * sizeof(T));
+    auto e_off = [&](int bl) { return unsigned((((j >> 1) * 64 + (y * BPW + bl)) * 12 + (j & 1) * 6) * sizeof(T)); };
     auto u_off = [&](int bl) { return unsigned(((((j >> 4) * 64) + (y * BPW + bl)) * 48 + 3 * (j & 15)) * sizeof(T)); };
 
     // inputs of one round of the stage phase (NBI beams per thread; beam i of round dp is pass dp NBI + i of the buffers):
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                     const T* bl = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(P.kfrag) + b_off);
                     auto fetch = [&](int spl) {
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) loop_ld3(ers, a_off0 + unsigned((16 * m * SPAD * 6 + spl * 12) * sizeof(T)), af[spl % D][m]);
+                        for (int m = 0; m < 4; ++m) loop_ld3(ers, a_off0 + unsigned((spl * 64 + 16 * m) * 12 * sizeof(T)), af[spl % D][m]);
                         if (loop_b_streamed<NB>(2, 3 * spl)) {
 #pragma unroll
                             for (int tt = 0; tt < 3; ++tt) bs[spl % D][tt] = bl[size_t(3 * spl + tt) * 64];
@@ -750,28 +750,32 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                             *own_at(own, pass, 3) = t2{oq[0], oq[1]}; *own_at(own, pass, 4) = t2{oq[2], ov[0]}; *own_at(own, pass, 5) = t2{ov[1], ov[2]};
                         }
                     }
-                    // ---- what the other workgroups read: the round's records are gathered in LDS as they lie in memory
-                    // ([beam][slot][q, v]: 6 KB contiguous per beam at NB = 8) and leave in 1 KB pieces per store instruction
-                    // (a write-through store costs a fabric write per lane unless the lanes of an instruction fill whole lines:
-                    // 48 bytes per thread straight from the registers took 7 us per stage, a quarter of it in the hand-off)
+                    // ---- what the other workgroups read.  The fragment buffer is [slot pair][64 beams][12 values]: the R = BPP NBI
+                    // beams of a round are neighbours in it, so per slot pair they form ONE contiguous segment of R x 96 bytes
+                    // (384 at NB = 8: three whole lines).  The round's records are gathered in LDS in that order and leave in
+                    // 1 KB pieces per store instruction -- whole lines: a write-through store costs a fabric write per lane
+                    // unless the lanes of an instruction fill lines (48 bytes per thread straight from the registers took 7 us
+                    // per stage, a quarter of it in the hand-off).
                     if (!(s == 3 && last_step)) {
+                        constexpr int R = BPP * NBI, SEG = R * 12 * int(sizeof(T)), PIECES = (SPAD / 2) * SEG / 1024;
+                        static_assert(((SPAD / 2) * SEG) % 4096 == 0, "whole 1 KB pieces, evenly over the waves");
                         unsigned char* stg = reinterpret_cast<unsigned char*>(scratch + size_t(BPP) * NBI * 3 * (NTB + 1));   // over the round-A columns
                         __syncthreads();   // (every wave has read its round-A columns)
 #pragma unroll
                         for (int i = 0; i < NBI; ++i) {
-                            t2* d = reinterpret_cast<t2*>(stg + ((sub * NBI + i) * SPAD + j) * 6 * sizeof(T));
+                            t2* d = reinterpret_cast<t2*>(stg + (((j >> 1) * R + i * BPP + sub) * 12 + (j & 1) * 6) * sizeof(T));
                             d[0] = t2{eo[i][0], eo[i][1]}; d[1] = t2{eo[i][2], eo[i][3]}; d[2] = t2{eo[i][4], eo[i][5]};
                         }
                         __syncthreads();
-                        constexpr int BEAM_BYTES = SPAD * 6 * int(sizeof(T)), PIECES = BPP * NBI * BEAM_BYTES / 1024;
-                        static_assert(BEAM_BYTES % 1024 == 0 && PIECES % 4 == 0, "whole 1 KB pieces, evenly over the waves");
+                        const unsigned g0 = unsigned((y * BPW + dp * R) * 12 * sizeof(T));   // the round's first beam inside a slot pair's 64
+                        unsigned l16 = unsigned(lane) * 16u;
+                        asm volatile("" : "+v"(l16));   // (the piece addresses are formed here, not hoisted into registers that live across the launch)
 #pragma unroll
                         for (int c = 0; c < PIECES / 4; ++c) {
-                            const int piece = c * 4 + wave;                                 // (wave: scalar)
-                            const int r = piece * 1024 / BEAM_BYTES, within = piece * 1024 - r * BEAM_BYTES;   // staged beam r = sub' NBI + i'
-                            const int bl_r = (dp * NBI + r % NBI) * BPP + r / NBI;          // its index among the workgroup's beams
-                            const loop_u4 v = *reinterpret_cast<const loop_u4*>(stg + piece * 1024 + lane * 16);
-                            __builtin_amdgcn_raw_buffer_store_b128(v, ers, unsigned((y * BPW + bl_r) * BEAM_BYTES + within + lane * 16), 0, LOOP_SC1);
+                            const unsigned q = unsigned((c * 4 + wave) * 1024) + l16;     // byte inside the gathered image
+                            const unsigned sp = q / unsigned(SEG), within = q - sp * unsigned(SEG);
+                            const loop_u4 v = *reinterpret_cast<const loop_u4*>(stg + q);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, ers, sp * unsigned(64 * 12 * sizeof(T)) + g0 + within, 0, LOOP_SC1);
                         }
                     }
                     cur = nxt;
