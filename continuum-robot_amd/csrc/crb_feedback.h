@@ -49,12 +49,6 @@ struct FeedbackParams {
 // unconditional (rows / columns out of range read a clamped address and are zeroed by a select) -- a load
 // under a per-lane branch would be followed by s_waitcnt vmcnt(0) inside the branch.  The reduced-index ->
 // state-offset table sits in LDS.
-#ifndef CRB_GEMM_SCHED
-#define CRB_GEMM_SCHED 0
-#endif
-#ifndef CRB_GEMM_WS_SCHED   // wave-specialised kernel: fragment reads of the next pair of sub-steps ahead of the current MFMAs
-#define CRB_GEMM_WS_SCHED 0  // (experiment switch, 1 / 2 / 3 = three interleavings: all measured SLOWER, 227 against 201 us per config-5 step)
-#endif
 template <typename T, int BM, int BN, int BK, int WR, bool HAS_REF>
 __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<T> p) {
     typedef typename MfmaOps<T>::acc_t crb_d4;
@@ -168,19 +162,6 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 #pragma unroll
             for (int i = 0; i < PPS; ++i) stash_piece(Rcur, st ^ 1, (kk >> 2) * PPS + i);
         }
-#if CRB_GEMM_SCHED
-        // a wave issues in order: an MFMA holds the matrix pipe for 64 cycles, and whatever follows it in
-        // program order can issue in that shadow only if it is not another MFMA.  Ask the scheduler for
-        // MFMA / LDS read / VALU / global load / LDS write round-robin instead of MFMA clusters.
-#pragma unroll
-        for (int i = 0; i < NSUB * TM * TN; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-#endif
         __syncthreads();
     };
     for (int sidx = 0; sidx < nsteps; sidx += 2) {
@@ -215,23 +196,13 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 // One barrier per K step, taken by both roles.  In-kernel cycle stamps at 2048 x 768 x 384 (64 x 48 tiles,
 // BK 64, 12 K steps): prologue 7.3k cycles (offset table, first tile), per step 3.6k cycles for 48 MFMAs
 // (75 each, 64 = pipe-bound) + 0.4-0.7k at the barrier; 32.7 us against 34.1 us for crb_feedback_kernel.
-#ifndef CRB_WS_NL       // loader threads of the wave-specialised kernel: 512 = two loader waves per SIMD behind the one matrix wave
-                        // (256 = one: config 5 200.9 -> 196.5 us per step with two)
-#define CRB_WS_NL 512
-#endif
-#ifndef CRB_WS_PROBE    // timing probes of the wave-specialised kernel (results are WRONG): 1 = loaders only, 2 = matrix waves only
-#define CRB_WS_PROBE 0
-#endif
-#ifndef CRB_WS_PRIO_M   // wave priorities of the two roles
-#define CRB_WS_PRIO_M 2
-#endif
-#ifndef CRB_WS_PRIO_L
-#define CRB_WS_PRIO_L 0
-#endif
+constexpr int WS_NL = 512;       // loader threads of the wave-specialised kernel: two loader waves per SIMD behind the one matrix wave
+                                 // (one: config 5 200.9 instead of 196.5 us per step)
+constexpr int WS_PRIO_M = 2, WS_PRIO_L = 0;   // wave priorities of the two roles (swapped or equal: no difference measured)
 template <typename T, int BN, int BK, bool HAS_REF>
-__global__ void __launch_bounds__(256 + CRB_WS_NL) crb_feedback_ws_kernel(const FeedbackParams<T> p) {
+__global__ void __launch_bounds__(256 + WS_NL) crb_feedback_ws_kernel(const FeedbackParams<T> p) {
     typedef typename MfmaOps<T>::acc_t crb_d4;
-    constexpr int BM = 64, TN = BN / 16, LD = BK + 2, NL = CRB_WS_NL;   // NL loader threads behind the 256 matrix threads
+    constexpr int BM = 64, TN = BN / 16, LD = BK + 2, NL = WS_NL;   // NL loader threads behind the 256 matrix threads
     constexpr int QA = BM * BK / NL, QB = BN * BK / NL, RSTEP = NL / BK;
     static_assert(BN % 16 == 0 && NL % BK == 0 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
@@ -246,7 +217,7 @@ __global__ void __launch_bounds__(256 + CRB_WS_NL) crb_feedback_ws_kernel(const 
 
     if (wave >= 4) {
         // ------------------------------------------------ loader role
-        __builtin_amdgcn_s_setprio(CRB_WS_PRIO_L);
+        __builtin_amdgcn_s_setprio(WS_PRIO_L);
         const int lt = t - 256;
         const int lk = lt & (BK - 1), lr = lt / BK;
         const T* xrow[QA];
@@ -288,11 +259,6 @@ __global__ void __launch_bounds__(256 + CRB_WS_NL) crb_feedback_ws_kernel(const 
 #pragma unroll
             for (int q = 0; q < QB; ++q) Bt[(lr + RSTEP * q) * LD + lk] = R.gb[q] * R.kmask;
         };
-#if CRB_WS_PROBE == 2   // (timing probe: loaders idle, the matrix waves run over whatever LDS holds)
-        __syncthreads();
-        for (int sidx = 0; sidx < nsteps; ++sidx) __syncthreads();
-        return;
-#endif
         fetch(R0, 0);
         fetch(R1, BK);
         stash(R0, 0);
@@ -310,16 +276,12 @@ __global__ void __launch_bounds__(256 + CRB_WS_NL) crb_feedback_ws_kernel(const 
         return;
     }
     // ---------------------------------------------------- matrix role
-    __builtin_amdgcn_s_setprio(CRB_WS_PRIO_M);
+    __builtin_amdgcn_s_setprio(WS_PRIO_M);
     crb_d4 acc[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[b] = crb_d4{T(0), T(0), T(0), T(0)};
     __syncthreads();                           // stage 0 ready
     for (int sidx = 0; sidx < nsteps; ++sidx) {
-#if CRB_WS_PROBE == 1   // (timing probe: matrix waves idle, the loaders alone set the pace)
-        __syncthreads();
-        continue;
-#endif
         const int st = sidx & 1;
         const T* Aw = As + st * BM * LD + (16 * wave + (lane & 15)) * LD + (lane >> 4);
         const T* Bw = Bs + st * BN * LD + (lane & 15) * LD + (lane >> 4);
@@ -338,44 +300,6 @@ __global__ void __launch_bounds__(256 + CRB_WS_NL) crb_feedback_ws_kernel(const 
 #pragma unroll
             for (int b = 0; b < TN; ++b) acc[b] = MfmaOps<T>::run(af[cur], bf[cur][b], acc[b]);
         }
-#if CRB_GEMM_WS_SCHED
-        // The fragment reads of two sub-steps come out as one ds_read2_b64 per operand (1 + TN reads for 2 TN MFMAs).  Left to
-        // itself the scheduler emits reads -> wait -> MFMAs per pair, so every pair starts with the LDS latency exposed (75
-        // instead of 64 cycles per MFMA, in-kernel stamps).  Asking for the reads of pair g + 1 IN FRONT of the MFMAs of pair g
-        // gives exactly that instruction stream -- and a kernel that is 6.5 us slower (33 % more time per K step), whichever
-        // of the three interleavings below and with the barrier pinned behind the last MFMA: with one matrix wave and one
-        // loader wave per SIMD the bubbles are presumably where the loader wave gets its stores issued.
-#if CRB_GEMM_WS_SCHED == 1
-        __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
-        }
-#elif CRB_GEMM_WS_SCHED == 2   // one read behind each of the first MFMAs of a pair
-        __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-#pragma unroll
-            for (int i = 0; i < 1 + TN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN - (1 + TN), 0);
-        }
-#elif CRB_GEMM_WS_SCHED == 3   // the reads of the next pair behind the first half of the current pair's MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1 + TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
-        }
-#endif
-        // (the barrier stays BEHIND the last MFMA: once the reads run ahead it would otherwise move up to the last read, and
-        //  the matrix waves would wait for the loaders with two pairs of MFMAs still to issue -- measured 229 against 200 us)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         __syncthreads();
     }
     // epilogue: D row (beam) = (lane>>4) + 4*reg, D col (output) = lane&15; scatter into the force layout

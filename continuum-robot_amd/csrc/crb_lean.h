@@ -19,9 +19,6 @@ namespace crb {
 //   * round A moves 16-byte LDS words (record = 10 fp64 / 12 fp32 values per thread, padded so
 //     that ds_read/write_b128 are bank-conflict free); lane +-1 shifts use DPP wave_shr/wave_shl
 //     (no LDS round trip), larger lane shifts ds_bpermute.
-#ifndef CRB_RECB_F32  // fp32 cross-wave levels as one 16-byte record per thread (0: three 4-byte columns)
-#define CRB_RECB_F32 1
-#endif
 template <typename T>
 struct LeanRec {                    // fp32: [qn0 qn1 qn2 - | p0 p1 p2 - | fl0 fl1 fl2 -]   (fp64: columns, see the stepper)
     static constexpr int N = sizeof(T) == 8 ? 10 : 12;   // 80 B / 48 B: conflict-free 16-byte accesses
@@ -33,7 +30,7 @@ __host__ __device__ constexpr size_t lean_lds_bytes(int NT, int lognw) {
     // barrier round) + SoA buffers (+1 zero column) of the cross-wave levels 1..lognw-1
     // (fp32: the cross-wave levels move one 16-byte record [r0 r1 r2 -] per thread instead of three 4-byte columns)
     return sizeof(T) * (size_t(NT + 1) * LeanRec<T>::N * (lognw == 1 ? 2 : 1) +
-                        ((sizeof(T) == 4 && CRB_RECB_F32) ? 4 : 3) * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
+                        (sizeof(T) == 4 ? 4 : 3) * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
 }
 
 // wave_shr:1 / wave_shl:1 with bound_ctrl: a lane without a source lane reads 0 and no "old" value has
@@ -60,61 +57,17 @@ __device__ __forceinline__ float dpp_from_higher(float x) {
 // LDS round trip; lanes shifted in from outside the wave read 0).  Larger D: ds_bpermute; a lane
 // index outside the wave wraps to some lane of the SAME beam -- callers only ever multiply such
 // a value by a multiplier that is exactly 0 (no neighbour at that stride).
-#ifndef CRB_DPP_MAX
-#define CRB_DPP_MAX 4
-#endif
-// wave priorities per phase of a stage (s_setprio; -1 = leave unchanged)
-#ifndef CRB_P_FORCE
-#define CRB_P_FORCE 0
-#endif
-#ifndef CRB_P_XCHG
-#define CRB_P_XCHG 2
-#endif
-#ifndef CRB_P_L1
-#define CRB_P_L1 -1
-#endif
-#ifndef CRB_P_TAIL
-#define CRB_P_TAIL 1
-#endif
-#ifndef CRB_P_FIN
-#define CRB_P_FIN -1
-#endif
-// fp32 plans (four waves per SIMD, LDS-issue-limited) want the priority to RISE through the stage and drop at its end
-// (measured on config 4: +3.7 % over the fp64 values; the fp64 stepper is indifferent to them or slower)
-#ifndef CRB_P32_L1
-#define CRB_P32_L1 3
-#endif
-#ifndef CRB_P32_TAIL
-#define CRB_P32_TAIL 3
-#endif
-#ifndef CRB_P32_FIN
-#define CRB_P32_FIN 0
-#endif
-#ifndef CRB_SOA
-#define CRB_SOA 1
-#endif
-#ifndef CRB_UNMERGED_F32   // the same for fp32 records (0: the merged round): 3 + 4 LDS instructions instead of 3 + 5
-#define CRB_UNMERGED_F32 1
-#endif
-#ifndef CRB_UNMERGED   // fp64 beams of several waves form r before exchanging it (0: the merged round {qn, p, fl})
-#define CRB_UNMERGED 1
-#endif
-#ifndef CRB_SOA_F32   // fp32 round A as 4-byte columns instead of 16-byte records (experiment switch)
-#define CRB_SOA_F32 0
-#endif
-// components (0..3) of the lane+-4 exchange that travel by ds_bpermute instead of four chained DPP moves per half:
-// the kernel is bound by vector-ALU issue, the LDS pipe has slack -- moving PART of the widest shift there balances
-// the two (all 12 ds_bpermute: LDS-issue-bound again, measured in round 1)
-#ifndef CRB_BPERM_C
-#define CRB_BPERM_C 0
-#endif
-#ifndef CRB_BPERM_C2   // the same for the lane+-2 exchange (two chained DPP moves per half)
-#define CRB_BPERM_C2 0
-#endif
+constexpr int LEAN_DPP_MAX = 4;   // lane shifts up to this distance are chained DPP moves, larger ones ds_bpermute
+// wave priorities per phase of a stage (s_setprio; -1 = leave unchanged): element force 0, exchanges and the cross-wave
+// level 2, in-wave levels 1 -- the two workgroups of a CU then interleave force arithmetic with the other's exchange
+// latency (+10 %).  fp32 plans (four waves per SIMD, LDS-issue-limited) want the priority to RISE through the stage and
+// drop at its end (config 4: +3.7 % over the fp64 values; the fp64 stepper is indifferent to those or slower).
+constexpr int P_FORCE = 0, P_XCHG = 2, P_L1 = -1, P_TAIL = 1, P_FIN = -1;
+constexpr int P32_L1 = 3, P32_TAIL = 3, P32_FIN = 0;
 #define CRB_SETPRIO(v) do { if ((v) >= 0) __builtin_amdgcn_s_setprio((v) < 0 ? 0 : (v)); } while (0)
 template <typename T, int D>
 __device__ __forceinline__ T lane_lower(T x, int lane) {
-    if (D <= CRB_DPP_MAX) {
+    if (D <= LEAN_DPP_MAX) {
 #pragma unroll
         for (int i = 0; i < D; ++i) x = dpp_from_lower(x);
         return x;
@@ -123,29 +76,12 @@ __device__ __forceinline__ T lane_lower(T x, int lane) {
 }
 template <typename T, int D>
 __device__ __forceinline__ T lane_higher(T x, int lane) {
-    if (D <= CRB_DPP_MAX) {
+    if (D <= LEAN_DPP_MAX) {
 #pragma unroll
         for (int i = 0; i < D; ++i) x = dpp_from_higher(x);
         return x;
     }
     return __shfl(x, lane + D, 64);
-}
-
-// 16-byte LDS access of the V values starting at element index I (I % V == 0) of a record
-template <typename T>
-struct Vec16 {
-    typedef T type __attribute__((ext_vector_type(16 / sizeof(T))));
-};
-template <typename T, int FIRST, int LAST>
-__device__ __forceinline__ void rec_load(const T* rec, T* out /*[N]*/) {
-    constexpr int V = LeanRec<T>::V;
-    typedef typename Vec16<T>::type vec;
-#pragma unroll
-    for (int w = FIRST / V; w <= LAST / V; ++w) {
-        const vec v = *reinterpret_cast<const vec*>(rec + w * V);
-#pragma unroll
-        for (int k = 0; k < V; ++k) out[w * V + k] = v[k];
-    }
 }
 
 // Reduction levels 1..LV-1 and the final block inverse of the lean kernels, given r after level 0.
@@ -166,7 +102,7 @@ __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* 
 #pragma unroll
     for (int l = 1; l < LV; ++l) {
         if (l < LOGNW) {  // another wave holds the neighbour: LDS + barrier
-            if (l == 1) CRB_SETPRIO(sizeof(T) == 4 ? CRB_P32_L1 : CRB_P_L1);
+            if (l == 1) CRB_SETPRIO(sizeof(T) == 4 ? P32_L1 : P_L1);
             const int st = 1 << l;
             const int tl = (valid && j - st >= 0) ? thread_of(j - st) : NULLT;
             const int th = (valid && j + st < S) ? thread_of(j + st) : NULLT;
@@ -186,19 +122,13 @@ __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* 
                 for (int c = 0; c < 3; ++c) { rlo[c] = buf[c * (NT + 1) + tl]; rhi[c] = buf[c * (NT + 1) + th]; }
             }
         } else {
-            if (l == LOGNW) CRB_SETPRIO(sizeof(T) == 4 ? CRB_P32_TAIL : CRB_P_TAIL);
+            if (l == LOGNW) CRB_SETPRIO(sizeof(T) == 4 ? P32_TAIL : P_TAIL);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 switch (l - LOGNW) {
                     case 0: rlo[c] = lane_lower<T, 1>(r[c], lane); rhi[c] = lane_higher<T, 1>(r[c], lane); break;
-                    case 1:
-                        if (c < CRB_BPERM_C2) { rlo[c] = __shfl(r[c], lane - 2, 64); rhi[c] = __shfl(r[c], lane + 2, 64); }
-                        else { rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); }
-                        break;
-                    case 2:
-                        if (c < CRB_BPERM_C) { rlo[c] = __shfl(r[c], lane - 4, 64); rhi[c] = __shfl(r[c], lane + 4, 64); }
-                        else { rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); }
-                        break;
+                    case 1: rlo[c] = lane_lower<T, 2>(r[c], lane); rhi[c] = lane_higher<T, 2>(r[c], lane); break;
+                    case 2: rlo[c] = lane_lower<T, 4>(r[c], lane); rhi[c] = lane_higher<T, 4>(r[c], lane); break;
                     case 3: rlo[c] = lane_lower<T, 8>(r[c], lane); rhi[c] = lane_higher<T, 8>(r[c], lane); break;
                     case 4: rlo[c] = lane_lower<T, 16>(r[c], lane); rhi[c] = lane_higher<T, 16>(r[c], lane); break;
                     default: rlo[c] = lane_lower<T, 32>(r[c], lane); rhi[c] = lane_higher<T, 32>(r[c], lane); break;
@@ -213,7 +143,7 @@ __device__ __forceinline__ void lean_reduce_tail(const SolveCoef<T, LV>& cf, T* 
         }
         pcr_apply_level<T>(cf.lv[l], rlo, rhi, r);
     }
-    CRB_SETPRIO(sizeof(T) == 4 ? CRB_P32_FIN : CRB_P_FIN);
+    CRB_SETPRIO(sizeof(T) == 4 ? P32_FIN : P_FIN);
     pcr_apply_final<T>(cf.fin, r, a);
 }
 
@@ -308,12 +238,12 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     KParams<T> p = CRB_PARAMS(kp);
     static_assert(!PACK || LOGNW == 0, "packed beams live inside one wave");
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
-    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N, RV = LeanRec<T>::V;
+    constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N;
     constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
     // fp64 round A is laid out as 9 columns [qn0..2 p0..2 fl0..2][NT+1] moved by 8-byte accesses (a 16-byte LDS
     // store costs 13 cycles of the store path against 2 x 6 for two 8-byte ones); fp32 keeps 16-byte records
-    constexpr bool SOA = CRB_SOA && (sizeof(T) == 8 || CRB_SOA_F32);
-    constexpr bool RECB = sizeof(T) == 4 && CRB_RECB_F32;   // cross-wave levels as 16-byte records (fp64: 32-byte records measured 4 % slower)
+    constexpr bool SOA = sizeof(T) == 8;
+    constexpr bool RECB = sizeof(T) == 4;   // cross-wave levels as 16-byte records (fp64: 32-byte records measured 4 % slower)
     auto recA = [](T* base, int th, int k) -> T& { return SOA ? base[size_t(k) * (NT + 1) + th] : base[size_t(th) * RN + k]; };
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
     T* const ldsA = reinterpret_cast<T*>(crb_smem);
@@ -461,11 +391,11 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
             }
             // -- element force of the element left of this node
             T fl[3], fr[3];
-            CRB_SETPRIO(CRB_P_FORCE);
+            CRB_SETPRIO(P_FORCE);
             if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
             else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
             else elem_force<T>(ec, qL, sq, corrected, fl, fr);
-            CRB_SETPRIO(CRB_P_XCHG);
+            CRB_SETPRIO(P_XCHG);
             T pp[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -513,7 +443,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
                 }
             } else {
                 T* bufA = ldsA + ((LOGNW == 1 && (s & 1)) ? size_t(NT + 1) * RN : 0);
-                if (SOA && CRB_UNMERGED) {
+                if (SOA) {
                     // r first (one exchange of {qn, fl}), then ITS stride-1 neighbours (a second one): the same 9 stores +
                     // 12 loads as the merged round {qn, p, fl}, 6 subtractions less, one barrier more -- the fp64 stepper is
                     // bound by vector-ALU issue, not by its barriers: 27.72 -> 27.18 us per step at 4096 x 256
@@ -529,21 +459,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
                     __syncthreads();
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { rlo[c] = recA(bufA, t_l1, 3 + c); rhi[c] = recA(bufA, t_r1, 3 + c); }
-                } else if (SOA) {
-                    recA(bufA, t, 0) = qn[0]; recA(bufA, t, 1) = qn[1]; recA(bufA, t, 2) = qn[2];
-                    recA(bufA, t, 3) = pp[0]; recA(bufA, t, 4) = pp[1]; recA(bufA, t, 5) = pp[2];
-                    recA(bufA, t, 6) = fl[0]; recA(bufA, t, 7) = fl[1]; recA(bufA, t, 8) = fl[2];
-                    __syncthreads();
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {   // what level 0 needs first, the next stage's qL last
-                        rlo[c] = recA(bufA, t_l1, 3 + c) - fl[c];
-                        r[c] = pp[c] - recA(bufA, t_r1, 6 + c);
-                        rhi[c] = recA(bufA, t_r1, 3 + c) - recA(bufA, t_r2, 6 + c);
-                    }
-                    if (GRAV) phiR = recA(bufA, t_r1, 2);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) qL[c] = recA(bufA, t_l1, c);
-                } else if (sizeof(T) == 4 && CRB_UNMERGED_F32) {
+                } else {
                     // fp32 records, r first: [qn0 qn1 qn2 - | fl0 fl1 fl2 -] out, the left neighbour's word 0 and the right
                     // one's word 1 (and its phi) in; then [r0 r1 r2 -] (word 2) out and both neighbours' in: 3 stores + 4 loads
                     typedef T rec4 __attribute__((ext_vector_type(4)));
@@ -561,39 +477,6 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
                     const rec4 rl = recs[size_t(t_l1) * W + 2], rr = recs[size_t(t_r1) * W + 2];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { rlo[c] = rl[c]; rhi[c] = rr[c]; }
-                } else {
-                typedef typename Vec16<T>::type vec;
-                // record: fp32 [qn0 qn1 qn2 - | p0 p1 p2 - | fl0 fl1 fl2 -] (each neighbour's read is whole 16-byte words:
-                // left {qn, p} = words 0-1, right {p, fl} = words 1-2, second right {fl} = word 2: five loads);
-                // fp64 (experiment switch CRB_SOA=0 only) [qn0 qn1 | qn2 - | p0 p1 | p2 fl0 | fl1 fl2]
-                constexpr int F0 = sizeof(T) == 4 ? 8 : 7;
-                T out[RN];
-#pragma unroll
-                for (int k = 0; k < RN; ++k) out[k] = T(0);
-                out[0] = qn[0]; out[1] = qn[1]; out[2] = qn[2];
-                out[4] = pp[0]; out[5] = pp[1]; out[6] = pp[2];
-                out[F0] = fl[0]; out[F0 + 1] = fl[1]; out[F0 + 2] = fl[2];
-                vec* rec = reinterpret_cast<vec*>(bufA + size_t(t) * RN);
-#pragma unroll
-                for (int wv = 0; wv < RN / RV; ++wv) {
-                    vec v;
-#pragma unroll
-                    for (int k = 0; k < RV; ++k) v[k] = out[wv * RV + k];
-                    rec[wv] = v;
-                }
-                __syncthreads();
-                T L[RN], R1[RN], R2[RN];
-                rec_load<T, 0, 6>(bufA + size_t(t_l1) * RN, L);
-                rec_load<T, GRAV ? 2 : 4, F0 + 2>(bufA + size_t(t_r1) * RN, R1);
-                rec_load<T, F0, F0 + 2>(bufA + size_t(t_r2) * RN, R2);
-                if (GRAV) phiR = R1[2];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    qL[c] = L[c];
-                    rlo[c] = L[4 + c] - fl[c];
-                    r[c] = pp[c] - R1[F0 + c];
-                    rhi[c] = R1[4 + c] - R2[F0 + c];
-                }
                 }
             }
             pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
@@ -654,26 +537,18 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
 // rotation for gravity) are plain global loads of the stage state: no exchange round for them.
 //   k = f(t_stage, xs, u_stage + impulse);  acc = (stage ? acc : 0) + w k;
 //   stage < 3: out = x + c k;   stage 3: x += dt/6 acc           (same contract as MODE_STAGE)
-#ifndef CRB_STAGE_IO   // node records through LDS in memory order (0: every thread loads / stores its own slot's records)
-#define CRB_STAGE_IO 1
-#endif
-#ifndef CRB_STAGE_PREFETCH   // load the next beam's records while the current beam is computed (needs CRB_STAGE_MINW=1: 56 more
-                             // registers; measured 21.6 vs 21.4 us at 2048 x 128, 24.6 vs 26.5 at 1024 x 256: off)
-#define CRB_STAGE_PREFETCH 0
-#endif
-#ifndef CRB_STAGE_MINW      // waves per SIMD the stage kernel's fp64 register allocation aims at
-#define CRB_STAGE_MINW 2
-#endif
+// Beams of two / four waves move their node records through LDS in memory order (see the kernel); loading the NEXT beam's
+// records one beam ahead was measured and is not taken (21.6 against 21.4 us at 2048 x 128, with 56 more registers).
 constexpr int STAGE_IO_STREAMS = 7;   // xs q / v, x q / v, acc q / v, u
 template <typename T>
 __host__ __device__ constexpr size_t stage_lean_lds_bytes(int NT, int lognw) {
     // exchange columns (16-byte multiple) + the record staging of the transposed I/O (beams of more than one wave)
     const size_t cols = sizeof(T) * (size_t(NT + 1) * 6 * (lognw == 1 ? 2 : 1) + 3 * size_t(NT + 1) * size_t(lognw > 1 ? lognw - 1 : 0));
-    const size_t io = (CRB_STAGE_IO && lognw > 0 && lognw <= 2) ? size_t(STAGE_IO_STREAMS) * size_t(NT + 1) * 4 * sizeof(T) : 0;   // (eight waves: no room)
+    const size_t io = (lognw > 0 && lognw <= 2) ? size_t(STAGE_IO_STREAMS) * size_t(NT + 1) * 4 * sizeof(T) : 0;   // (eight waves: no room)
     return ((cols + 31) / 32) * 32 + io;
 }
 template <typename T, int LV, int LOGNW, bool GRAV, int EM>
-__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : CRB_STAGE_MINW) crb_stage_lean_kernel(const KParams<T> p) {
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_stage_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stage kernel needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];
@@ -685,7 +560,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
     // of node t -- consecutive lanes, consecutive records -- and the records change hands in LDS: staged at the position
     // of the OWNER thread (so that the owner and its stride-1 neighbours read consecutive positions), which also hands
     // the left neighbour's q and the right neighbour's rotation over without loads of their own.
-    constexpr bool IO = CRB_STAGE_IO && LOGNW > 0 && LOGNW <= 2;
+    constexpr bool IO = LOGNW > 0 && LOGNW <= 2;
     typedef T rec4 __attribute__((ext_vector_type(4)));
     constexpr size_t COLS_BYTES = ((sizeof(T) * (size_t(NT + 1) * 6 * (LOGNW == 1 ? 2 : 1) + 3 * size_t(NT + 1) * size_t(LOGNW > 1 ? LOGNW - 1 : 0)) + 31) / 32) * 32;
     rec4* const io = reinterpret_cast<rec4*>(crb_smem + COLS_BYTES);        // [7][NT+1] records, position NT = zeros
@@ -769,11 +644,10 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
             if (p.u_held) pre[6] = ldrec(p.u_held + size_t(beam) * plane + mnode * 4);
         }
     };
-    if (IO && CRB_STAGE_PREFETCH) fetch_io(blockIdx.x);
     int it = 0;
     for (int beam = blockIdx.x; beam < p.B; beam += gridDim.x, ++it) {
         if (!shared_tables) load_tables(beam);
-        if (IO && !CRB_STAGE_PREFETCH) fetch_io(beam);
+        if (IO) fetch_io(beam);
         // ---- this stage's state, the neighbours' pieces of it, the input force
         const size_t xoff = size_t(beam) * 2 * plane + node * 4;
         T sq[3] = {T(0), T(0), T(0)}, sv[3] = {T(0), T(0), T(0)}, qL[3] = {T(0), T(0), T(0)}, uin[3] = {T(0), T(0), T(0)};
@@ -786,10 +660,6 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 for (int k = 0; k < STAGE_IO_STREAMS; ++k) at(k, mpos) = pre[k];
             }
             __syncthreads();
-            if (CRB_STAGE_PREFETCH) {   // the next beam's records travel while this one is computed
-                fetch_io(beam + int(gridDim.x));
-                __builtin_amdgcn_sched_barrier(0);
-            }
             const int own = valid ? t : NULLT;
             const rec4 rq = at(0, own), rv = at(1, own), bq = at(2, own), bv = at(3, own), cq = at(4, own), cv = at(5, own), ru = at(6, own);
             const rec4 rl = at(0, t_l1);
@@ -833,11 +703,11 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
         }
         // ---- forces on this node from its own element, drag, gravity, inputs
         T fl[3], fr[3];
-        CRB_SETPRIO(CRB_P_FORCE);
+        CRB_SETPRIO(P_FORCE);
         if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, sq, false, fl, fr);
         else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, sq, fl, fr);
         else elem_force<T>(ec, qL, sq, corrected, fl, fr);
-        CRB_SETPRIO(CRB_P_XCHG);
+        CRB_SETPRIO(P_XCHG);
         T pp[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) pp[c] = uin[c] + ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];

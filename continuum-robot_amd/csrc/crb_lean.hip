@@ -113,13 +113,10 @@ hipError_t by_lv(const KParams<T>& k, int n, int levels, int lognw, int em, hipS
         default: return hipErrorInvalidValue;
     }
 }
-#ifndef CRB_RK45_MINW
-#define CRB_RK45_MINW 2
-#endif
 template <int LV, int LNW, int EM>
 hipError_t one_rk45(const KParams<T>& k, const Rk45Params& q, int n_beams, hipStream_t st) {
     constexpr int NT = 64 << LNW;
-    constexpr int MINW = CRB_RK45_MINW;   // waves per SIMD the register allocation aims at
+    constexpr int MINW = 2;   // waves per SIMD the register allocation aims at
     const size_t smem = rk45_lds_bytes<T>(NT, true);
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(crb_rk45_kernel<T, LV, 256, MINW, LNW, EM>),

@@ -46,9 +46,7 @@ constexpr int LOOP_SC1 = 16;            // aux bit of the raw buffer intrinsics:
 #ifndef CRB_LOOP_PROF                   // 1: every workgroup adds its time per phase (100 MHz ticks) to sync words [2 .. 13] (tuning builds)
 #define CRB_LOOP_PROF 0
 #endif
-#ifndef CRB_LOOP_DEPTH                  // slot pairs of A fragments in flight ahead of the MFMAs (24 VGPRs each)
-#define CRB_LOOP_DEPTH 4
-#endif
+constexpr int LOOP_DEPTH = 4;           // register sets of the A operand's ring: the loads of three slot pairs fly ahead of the MFMAs (24 + 6 VGPRs each)
 
 template <typename T>
 struct LoopParams {
@@ -123,16 +121,14 @@ __device__ __forceinline__ void loop_st6(__amdgpu_buffer_rsrc_t r, unsigned off,
 // fragments sit in accumulator registers (which vector-ALU code cannot touch, so the stage phase cannot evict them), the
 // sums and the streamed operands in vector registers.  Left to the compiler the sums take the accumulator file, a third
 // of the slice spills to scratch and the A loads sink to their first use.
-// Not all of it is resident: the last LOOP_BSTREAM k-steps of the third column tile are re-read from L2 in every GEMM
+// Not all of it is resident: the last LOOP_BSTREAM (36) k-steps of the third column tile are re-read from L2 in every GEMM
 // phase, riding in the A operand's register ring (coalesced 512-byte loads, +18 % on the A stream at 36 of 144) -- the
 // accumulator file then keeps room for what the stage phase parks there, instead of the compiler evicting fragments to
 // scratch.
-#ifndef CRB_LOOP_BSTREAM
-#define CRB_LOOP_BSTREAM 36
-#endif
+constexpr int LOOP_BSTREAM = 36;
 template <int NB>
 __host__ __device__ constexpr int loop_n_streamed() {   // k-steps of column tile 2 that are streamed (a multiple of 3: whole slot pairs)
-    return 18 * NB > 128 ? (CRB_LOOP_BSTREAM > 18 * NB - 126 ? CRB_LOOP_BSTREAM : 18 * NB - 126) : 0;
+    return 18 * NB > 128 ? (LOOP_BSTREAM > 18 * NB - 126 ? LOOP_BSTREAM : 18 * NB - 126) : 0;
 }
 template <int NB>
 __host__ __device__ constexpr bool loop_b_streamed(int n, int ks) { return n == 2 && ks >= 6 * NB - loop_n_streamed<NB>(); }
@@ -322,7 +318,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     static_assert(sizeof(T) == 8, "the persistent closed-loop stepper is built for fp64 plans");
     typedef typename MfmaOps<T>::acc_t acc4;
     typedef T t2 __attribute__((ext_vector_type(2)));
-    constexpr int SPAD = 16 * NB, NCOL = 3 * SPAD, SPW = 2 * NB, KSW = 3 * SPW, D = CRB_LOOP_DEPTH;
+    constexpr int SPAD = 16 * NB, NCOL = 3 * SPAD, SPW = 2 * NB, KSW = 3 * SPW, D = LOOP_DEPTH;
     constexpr int NTB = 64 << LOGNW, BPP = 256 / NTB, BPW = 64 / NB, NPASS = BPW / BPP, NLI = BPW * NTB;
     static_assert(SPAD == NTB, "one thread per padded slot");
     static_assert(NPASS * BPP == BPW && BPW * NB == 64, "beams of a row block divide evenly");

@@ -163,13 +163,10 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<
 // nearest-neighbour form: compile-time topology, one exchange of {q_m, a_m} for the element force and the K0 a term, the
 // merged {p, f_left} + level-0 round, levels inside the wave by DPP / ds_bpermute; the workgroup walks over beams with
 // its rows of A's tables in registers (all LV = ceil(log2 S) levels: 85 values at 256 slots, one wave per SIMD).
-#ifndef CRB_IMPLICIT_MINW5
-#define CRB_IMPLICIT_MINW5 2
-#endif
 // waves per SIMD the lean implicit kernels are built for: up to 5 levels the tables are no larger than the explicit
 // stepper's (two waves), 6 levels fit as well without the gravity terms (with them: >100 spilled registers), the full
 // 7 / 8 levels of long beams take the register file whole
-__host__ __device__ constexpr int implicit_lean_minw(int lv, bool grav) { return (lv <= 5 || (lv == 6 && !grav)) ? CRB_IMPLICIT_MINW5 : 1; }
+__host__ __device__ constexpr int implicit_lean_minw(int lv, bool grav) { return (lv <= 5 || (lv == 6 && !grav)) ? 2 : 1; }
 template <typename T>
 __host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) {
     return sizeof(T) * size_t(NT + 1) * size_t(12 + 3 * (lognw > 1 ? lognw - 1 : 0));

@@ -1806,10 +1806,10 @@ int launch_feedback_ws(const FeedbackParams<T>& f, hipStream_t st) {
     const size_t smem = feedback_lds_bytes<T, 64, BN, BK>(f.n2);
     if (f.ref) {
         if (int rc = allow_lds(crb_feedback_ws_kernel<T, BN, BK, true>, smem)) return rc;
-        hipLaunchKernelGGL((crb_feedback_ws_kernel<T, BN, BK, true>), grid, dim3(256 + CRB_WS_NL), smem, st, f);
+        hipLaunchKernelGGL((crb_feedback_ws_kernel<T, BN, BK, true>), grid, dim3(256 + WS_NL), smem, st, f);
     } else {
         if (int rc = allow_lds(crb_feedback_ws_kernel<T, BN, BK, false>, smem)) return rc;
-        hipLaunchKernelGGL((crb_feedback_ws_kernel<T, BN, BK, false>), grid, dim3(256 + CRB_WS_NL), smem, st, f);
+        hipLaunchKernelGGL((crb_feedback_ws_kernel<T, BN, BK, false>), grid, dim3(256 + WS_NL), smem, st, f);
     }
     return CRB_OK;
 }

@@ -1758,6 +1758,108 @@ def test_fused_feedback_stepper_matches_the_stage_split_one_and_the_oracle(n_e, 
     assert_blocks(ens2.unpack_state().cpu().numpy(), got, ens.free_index, 1e-10)
 
 
+@pytest.mark.parametrize("n_e,B,kind,kw,bcs,with_ref,groups", [
+    (128, 70, "linear", dict(enable_gravity=True), None, False, None),      # config 5's shape, two row blocks (the second ragged)
+    (128, 200, "linear", dict(enable_gravity=True), None, True, 2),          # four row blocks on two groups: groups walk; reference
+    (100, 64, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), None, False, None),   # padding slots, per-lane element branch
+    (70, 65, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True), None, True, None),
+    (64, 130, "linear", dict(enable_gravity=True), None, False, None),      # one wave per beam: groups of four workgroups
+    (40, 65, "linear", dict(), None, True, 1),
+    (96, 66, "linear", dict(enable_gravity=False), "pinned_tip", True, None),   # constrained DOFs inside the padded slot order
+])
+def test_persistent_closed_loop_stepper_matches_the_oracle_and_the_stage_split_path(n_e, B, kind, kw, bcs, with_ref, groups, monkeypatch):
+    """crb_loop_kernel (csrc/crb_loop.h): the closed-loop rollout of lqr_control.py:95-125 as ONE persistent launch -- groups
+    of workgroups own 64 beams, keep their slice of the gain in registers, alternate between the fp64-MFMA product and
+    the stage arithmetic and hand tiles to each other through L2.  Against RK4 over the oracle RHS with u = K (r - x) in
+    every stage, per DOF block, per-beam amplitudes (and references) from random states -- first / last beam of every row
+    block of 64 and the ones next to the block borders -- and against the stage-split path (CRB_LOOP=0), every beam."""
+    monkeypatch.setenv("CRB_LOOP", "1")
+    if groups:
+        monkeypatch.setenv("CRB_LOOP_MAX_GROUPS", str(groups))
+    rng = np.random.default_rng(1000 + n_e + B)
+    kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)] if kind == "mixed" else kind
+    bc = None
+    if bcs == "pinned_tip":
+        bc = ["FIXED"] + ["NONE"] * (n_e - 1)
+        bc[n_e // 2] = "PINNED"
+    cols = nitinol_columns(n_e, kinds, bc) if bc else nitinol_columns(n_e, kinds)
+    ens = ensemble(cols, B, kw)
+    n = ens.n
+    gain = rng.normal(0.0, 2e-2, (n, 2 * n))
+    ref = rng.normal(0.0, 1e-4, (B, 2 * n)) if with_ref else None
+    x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
+    amps = 0.05 * (1.0 + np.arange(B) / B)
+    steps, dt = 14, 2e-5
+    ens.set_state(x0)
+    t = ens.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps, impulse_duration=6.5 * dt)
+    assert ens.feedback_status() == 0
+    got = ens.unpack_state().cpu().numpy()
+    assert np.isfinite(got).all()
+    ob = oracle_beam(cols, **kw)
+    for b in sorted({0, 1, 7, 8, 62, 63, 64 % B, 65 % B, B // 2, B - 2, B - 1}):
+        want = ob.rk4_feedback(x0[b], dt, steps, gain, reference=None if ref is None else ref[b], amp=amps[b], duration=6.5 * dt)
+        assert_blocks(got[b], want, ens.free_index, 1e-10, what=b)
+    # a second call continues from where the first one stopped (fresh buffers, same clock): equal to one rollout of twice the length
+    ens.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps, impulse_duration=6.5 * dt)
+    ens_long = ensemble(cols, B, kw)
+    ens_long.set_state(x0)
+    ens_long.step_feedback(2 * steps, dt, gain, reference=ref, impulse_amp=amps, impulse_duration=6.5 * dt)
+    assert torch.equal(ens.state, ens_long.state)
+    monkeypatch.setenv("CRB_LOOP", "0")
+    ens2 = ensemble(cols, B, kw)
+    ens2.set_state(x0)
+    t2 = ens2.step_feedback(steps, dt, gain, reference=ref, impulse_amp=amps, impulse_duration=6.5 * dt)
+    assert t2 == t
+    assert_blocks(ens2.unpack_state().cpu().numpy(), got, ens.free_index, 1e-10)
+
+
+def test_persistent_closed_loop_stepper_with_release_acquire_fences(monkeypatch):
+    """The same launch with agent-scope release / acquire fences around every hand-off (CRB_LOOP_FENCES=1: the memory model's
+    own form, 50 us per step dearer) gives bitwise the result of the write-through / L1-bypassing form it ships with."""
+    monkeypatch.setenv("CRB_LOOP", "1")
+    cols = nitinol_columns(128, "linear")
+    kw = dict(enable_gravity=True)
+    rng = np.random.default_rng(5)
+    B = 130
+    outs = []
+    for fences in ("0", "1"):
+        monkeypatch.setenv("CRB_LOOP_FENCES", fences)
+        ens = ensemble(cols, B, kw)
+        n = ens.n
+        if not outs:
+            gain = rng.normal(0.0, 2e-2, (n, 2 * n))
+            x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
+        ens.set_state(x0)
+        ens.step_feedback(10, 2e-5, gain, impulse_amp=np.full(B, 0.1))
+        assert ens.feedback_status() == 0
+        outs.append(ens.state.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_full_size_config5_total_on_one_gpu():
+    """BASELINE config 5's TOTAL -- 16384 beams x 128 linear elements + gravity, LQR feedback per stage -- on one GPU: 256 row
+    blocks on the 32 resident groups of the persistent stepper (each group rolls eight row blocks out, one after the
+    other).  A dense random gain of the real one's size, 40 steps; a beam of every eighth row block against the oracle."""
+    cols = nitinol_columns(128, "linear")
+    kw = dict(enable_gravity=True)
+    B, steps, dt = 16384, 40, 5e-6
+    ens = ensemble(cols, B, kw)
+    n = ens.n
+    rng = np.random.default_rng(77)
+    gain = rng.normal(0.0, 2e-2, (n, 2 * n))
+    x0 = np.concatenate([rng.normal(0, 1e-5, (B, n)), rng.normal(0, 1e-3, (B, n))], axis=1)
+    amps = 10.0 * (1.0 + np.arange(B) / B)
+    ens.set_state(x0)
+    ens.step_feedback(steps, dt, gain, impulse_amp=amps)
+    assert ens.feedback_status() == 0
+    got = ens.unpack_state().cpu().numpy()
+    assert np.isfinite(got).all()
+    ob = oracle_beam(cols, **kw)
+    for b in list(range(5, B, 8 * 64 + 9)) + [B - 1]:
+        want = ob.rk4_feedback(x0[b], dt, steps, gain, amp=amps[b])
+        assert_blocks(got[b], want, ens.free_index, 1e-10, what=b)
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """`python bench.py --gpus 2` end to end on this ONE GPU (CRB_BENCH_REHEARSAL=1: both ranks on GPU 0, the exchange
     over gloo): the launcher, the shards, the chunked rollout with its asynchronous all-gather, the max-reduced clock
