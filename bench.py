@@ -62,7 +62,7 @@ CONFIGS = {
     "config2": dict(beams=1024, total=1024, elems=64, kind="linear", drag=False, gravity=True, x0=True, scaling="weak",
                     label="1024 beams x 64 elem, linear + gravity, fp64"),
     # LQR rollout ensemble (BASELINE config 5: 16384 beams, 2048 per GPU on 8 GPUs): state feedback u = K(0 - x) at
-    # every RK4 stage (stage-split path: one GEMM + one stage kernel per stage).  dt = 5e-6: the closed loop has
+    # every RK4 stage, the whole rollout ONE persistent launch (csrc/crb_loop.h).  dt = 5e-6: the closed loop has
     # |lambda|max = 3.2e5 1/s, RK4 is unstable at the open-loop dt = 2e-5.
     "config5": dict(beams=2048, total=16384, elems=128, kind="linear", drag=False, gravity=True, x0=True, lqr=True,
                     dt=5e-6, amp=10.0, scaling="weak",
@@ -185,10 +185,18 @@ def cpu_baseline(cols, kw, n_elem, target_s=10.0):
 
     ob = oracle_beam(cols, **kw)
     try:
-        cores = len(os.sched_getaffinity(0))   # a 1-GPU box's share is 16 of the host's cores
+        avail = len(os.sched_getaffinity(0))   # the cores this process may run on
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("CRB_BENCH_CPU_THREADS", "64"))))
+        avail = os.cpu_count() or 1
+    # every core the process may use (CRB_BENCH_CPU_THREADS caps it for debugging).  The cgroup's CPU quota is reported next to
+    # it: a 1-GPU box of the pool is a share of a 256-thread host, and threads beyond the quota are throttled, not refused.
+    cores = max(1, min(avail, int(os.environ.get("CRB_BENCH_CPU_THREADS", str(avail)))))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
     t0 = time.perf_counter()
     ob.rk4_impulse(np.zeros(2 * ob.n), 2e-5, 20, 0.1)
     per_beam_step = (time.perf_counter() - t0) / 20
@@ -208,9 +216,25 @@ def cpu_baseline(cols, kw, n_elem, target_s=10.0):
     out = sample(cores, target_s)
     out["kind"] = "port"
     out["host_cpu_count"] = os.cpu_count()
+    out["cores_available"] = avail
+    out["cgroup_cpu_quota"] = quota
+    out["cores_note"] = ("OpenMP threads = every core in the process's affinity mask" +
+                         (f"; the container's CPU quota is {quota:g} cores, so more threads than that share the quota" if quota else ""))
     out["one_core"] = sample(1, 0.6 * target_s)
     out["reference_python_1core"] = 3796.0   # BASELINE.md §2, measured in the survey container (reference proper)
     return out
+
+
+def source_hash(files):
+    """sha256 (first 16 hex digits) over the named kernel sources: profiles/traffic.json entries carry the hash of the sources
+    they were measured on, and a counter figure is only printed for the code it belongs to."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def worker(args):
@@ -500,55 +524,37 @@ def worker(args):
 
     # ---- roofline of the dominant kernel
     if gain is None:
+        # `frac` is the task contract's figure: ALGORITHMIC bytes (96 / 48 B per element-step) over the launch time
+        # against the HBM peak.  It is a nominal figure: the state lives in registers for the whole launch, real HBM traffic is
+        # `traffic` (`hbm_real_frac` of the peak), and what binds is named in `bound` with its own utilisation.
         algo_bytes_launch = BYTES_PER_ELEM_STEP[args.dtype] * Bc * ne * per_launch   # (per launch: one chunk's beams)
         achieved = algo_bytes_launch / avg_launch_s / 1e9
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        roofline = {"bound": "valu_fp64" if args.dtype == "f64" else "lds_issue",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "frac_is": "algorithmic bytes / launch time / HBM peak (contract accounting; the limiter is `bound`)",
+                    "traffic": None, "hbm_real_frac": None,
                     "kernel": "crb_implicit_lean_kernel" if cfg.get("implicit") else "crb_step_lean_kernel",
                     "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_launch,
                     "valu_issue_frac": None}
     else:
-        # config 5: the dominant kernel is the feedback GEMM U = (R - X) K^T on the fp64 matrix cores;
-        # both kernels of a stage are timed on their own here, live, with HIP events on the launch stream
-        lib = nat.load()
-        vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        u = torch.zeros((B, ens.n_node, 4), dtype=dtype, device=ens.device)
-        acc, nxt = torch.empty_like(ens.state), torch.empty_like(ens.state)
-        stream = C.c_void_p(torch.cuda.current_stream(ens.device).cuda_stream)
-        reps = 50
-
-        def time_kernel(fn):
-            for _ in range(5):
-                fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) * 1e-3 / reps
-
-        gemm_s = time_kernel(lambda: nat.check(lib.crb_feedback_force(ens.plan.h, vp(ens.state), vp(gain), None, vp(u), stream)))
-        stage_s = time_kernel(lambda: nat.check(lib.crb_rk4_stage(ens.plan.h, vp(ens.state), vp(ens.state), vp(acc), vp(nxt),
-                                                                  vp(u), 1, 0.0, dt, None, stream)))
+        # config 5: the closed loop is ONE persistent launch (crb_loop_kernel): four fp64-MFMA products U = (R - X) K^T per step
+        # inside it.  The roofline is the matrix work of the launch over its duration against the fp64 matrix peak.
         n = ens.n
         gemm_flop = 2.0 * B * (2 * n) * n
         peak_tf = MFMA_F64_PEAK_TF if args.dtype == "f64" else MFMA_F32_PEAK_TF
-        ach_tf = gemm_flop / gemm_s / 1e12
-        itemsize = 8 if args.dtype == "f64" else 4
-        stage_bytes = 12 * 4 * itemsize * B * ne     # 8 record reads + 4 record writes of 4 values per node-stage
         step_s = avg_launch_s / per_launch
+        flop_launch = 4 * gemm_flop * per_launch
+        ach_tf = flop_launch / avg_launch_s / 1e12
+        persistent = int(ens.feedback_path() == "persistent")
         roofline = {"bound": "mfma_f64" if args.dtype == "f64" else "mfma_f32", "achieved": ach_tf, "peak": peak_tf,
-                    "unit": "TFLOP/s", "frac": ach_tf / peak_tf, "traffic": None,
-                    "kernel": "crb_feedback_ws_kernel", "avg_launch_ms": gemm_s * 1e3,
-                    "algorithmic_flop_per_launch": gemm_flop,
-                    "whole_step": {"flop": 4 * gemm_flop, "ms": step_s * 1e3, "achieved": 4 * gemm_flop / step_s / 1e12,
-                                   "frac": 4 * gemm_flop / step_s / 1e12 / peak_tf,
-                                   "launches_per_step": 8},
-                    "stage_kernel": {"kernel": "crb_stage_lean_kernel", "bound": "hbm", "avg_launch_ms": stage_s * 1e3,
-                                     "algorithmic_bytes_per_launch": stage_bytes,
-                                     "achieved": stage_bytes / stage_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": stage_bytes / stage_s / 1e9 / HBM_PEAK_GBS}}
+                    "unit": "TFLOP/s", "frac": ach_tf / peak_tf, "traffic": None, "hbm_real_frac": None,
+                    "kernel": "crb_loop_kernel" if persistent else "crb_feedback_ws_kernel + crb_stage_lean_kernel",
+                    "avg_launch_ms": avg_launch_s * 1e3, "steps_per_launch": per_launch,
+                    "algorithmic_flop_per_launch": flop_launch,
+                    "launches_per_step": (1.0 / per_launch) if persistent else 8,
+                    "us_per_step": step_s * 1e6,
+                    "matrix_time_floor_us_per_step": 4 * gemm_flop / (peak_tf * 1e12) * 1e6,
+                    "feedback_status": ens.feedback_status()}
 
     if rank == 0:
         value = B_total * ne * args.steps / wall
@@ -589,27 +595,42 @@ def worker(args):
         if os.path.exists(traffic_file) and world == 1 and n_chunks == 1:
             try:
                 tj = json.load(open(traffic_file))
-                # HBM traffic of a stepper launch is one read + one write of the state, whatever the number of fused
-                # steps: keyed by config and dtype only (PMC passes of profiles/pmc_traffic.sh)
+                # HBM traffic of a launch is one read + one write of the state, whatever the number of fused steps: keyed by
+                # config and dtype only (PMC passes of profiles/r03_profile.sh).  An entry names the kernel sources it was
+                # measured on and their hash: if the sources have changed since, the figure is not this build's and is withheld.
                 key = f"{args.config}:{args.dtype}" + (":hetero" if args.hetero else "")
-                if key in tj:
-                    out["roofline"]["traffic"] = tj[key]["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = tj[key].get("source")
-                    if "stage_kernel" in out["roofline"] and "stage_kernel_hbm_bytes_per_launch" in tj[key]:
-                        out["roofline"]["stage_kernel"]["traffic"] = tj[key]["stage_kernel_hbm_bytes_per_launch"]
-                        out["roofline"]["stage_kernel"]["traffic_source"] = tj[key].get("stage_kernel_source")
-                    if "valu_instr_per_elem_step" in tj[key] and gain is None:
+                ent = tj.get(key)
+                if ent and ent.get("sources") and source_hash(ent["sources"]) != ent.get("sources_sha256_16"):
+                    print(f"[bench] WARNING: profiles/traffic.json[{key}] was measured on other kernel sources "
+                          f"({ent.get('sources_sha256_16')} != {source_hash(ent['sources'])}): traffic withheld -- re-run profiles/r03_profile.sh",
+                          file=sys.stderr)
+                    out["roofline"]["traffic_stale"] = True
+                    ent = None
+                if ent:
+                    out["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = ent.get("source")
+                    out["roofline"]["hbm_real_frac"] = ent["hbm_bytes_per_launch"] / avg_launch_s / (HBM_PEAK_GBS * 1e9)
+                    if "launch_steps" in ent and ent["launch_steps"] != per_launch:
+                        # (the persistent closed-loop launch moves bytes per STEP through L2 / MALL; its HBM figure belongs to the
+                        #  launch length it was measured at)
+                        out["roofline"]["traffic"] = None
+                        out["roofline"]["hbm_real_frac"] = None
+                        out["roofline"]["traffic_note"] = f"measured at {ent['launch_steps']} steps per launch; this run: {per_launch}"
+                    if "phases_us_per_stage" in ent:
+                        out["roofline"]["phases_us_per_stage"] = ent["phases_us_per_stage"]
+                        out["roofline"]["phases_source"] = ent.get("phases_source")
+                    if "valu_instr_per_elem_step" in ent and gain is None:
                         # the limiter that actually binds: vector-ALU issue slots (one wave instruction per
                         # SIMD every 4 cycles, 1024 SIMDs, nominal 2.4 GHz), instruction count from the PMC run
                         # (fp64 plans: every vector instruction of that kernel holds the port for 4 cycles, measured.
                         #  fp32 arithmetic issues faster than that -- the same formula gives 1.19 for config 4 -- so
                         #  the fp32 line carries the instruction rate instead of a fraction)
-                        lane_instr = tj[key]["valu_instr_per_elem_step"] * Bc * ne * per_launch / avg_launch_s
+                        lane_instr = ent["valu_instr_per_elem_step"] * Bc * ne * per_launch / avg_launch_s
                         if args.dtype == "f64":
                             out["roofline"]["valu_issue_frac"] = lane_instr / (1024 * 64 * VALU_CLOCK_HZ / 4)
                         else:
                             out["roofline"]["valu_wave_instr_per_s_per_simd"] = lane_instr / 64 / 1024
-                        out["roofline"]["valu_source"] = tj[key].get("valu_source")
+                        out["roofline"]["valu_source"] = ent.get("valu_source")
             except Exception as e:  # a malformed side file must not cost the run its result line
                 print(f"[bench] profiles/traffic.json ignored: {e}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:

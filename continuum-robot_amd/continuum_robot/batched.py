@@ -721,6 +721,11 @@ class BeamEnsemble:
         self.time = float(t_end.value)
         return self.time
 
+    def feedback_path(self) -> str:
+        """Which form `step_feedback` takes for this ensemble: "persistent" (one launch per rollout, csrc/crb_loop.h), "fused"
+        (small beams, gain in LDS) or "stage-split" (one GEMM + one stage launch per RK4 stage)."""
+        return {0: "stage-split", 1: "fused", 2: "persistent"}[int(self._lib.crb_feedback_path(self.plan.h))]
+
     def feedback_status(self) -> int:
         """0, or which hand-off of the last `step_feedback` gave up (the persistent stepper's workgroups wait for each
         other with a time limit instead of hanging the device; the state is unusable then).  Synchronises the stream."""

@@ -1437,6 +1437,13 @@ extern "C" size_t crb_feedback_work_bytes(const crb_plan* p) {
     return need;
 }
 
+static bool fused_feedback_eligible(const crb_plan* p, const crb_input_desc* in);
+extern "C" int crb_feedback_path(const crb_plan* p) {
+    if (!p || p->device < 0) return 0;
+    if (loop_eligible(p, nullptr)) return 2;
+    return fused_feedback_eligible(p, nullptr) ? 1 : 0;
+}
+
 extern "C" int crb_feedback_status(const crb_plan* p, const void* work, int32_t* status, void* stream) {
     if (int rc = need_device(p, "crb_feedback_status")) return rc;
     if (!work || !status) return fail(CRB_EINVAL, "crb_feedback_status: null pointer");
@@ -1467,10 +1474,9 @@ int feedback_step_launches(const crb_plan* p, void* x, void* acc, void* const bu
 }
 }  // namespace
 
-namespace {
 // Beams that live in one wave and whose gain fits LDS: the whole closed-loop rollout as ONE launch of the general
 // stepper's feedback instantiation (crb_generic.h, FB) instead of eight launches per step.
-bool fused_feedback_eligible(const crb_plan* p, const crb_input_desc* in) {
+static bool fused_feedback_eligible(const crb_plan* p, const crb_input_desc* in) {
     if (p->lognw != 0 || p->NT != 64 || p->mixed_topology || (in && in->f_held)) return false;
     const char* env = std::getenv("CRB_FUSED_FEEDBACK");     // 0 = never, 1 = whenever the gain fits LDS, unset = choose
     if (env && std::atoi(env) == 0) return false;
@@ -1484,6 +1490,7 @@ bool fused_feedback_eligible(const crb_plan* p, const crb_input_desc* in) {
     const size_t groups = size_t((p->B + p->G - 1) / p->G);
     return need <= size_t(52) * 1024 || groups <= per_cu * 256;
 }
+namespace {
 template <typename T, int LV>
 int launch_fused_feedback_lv(const crb_plan* p, const KParams<T>& k, hipStream_t st) {
     const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);

@@ -272,6 +272,8 @@ int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void
  * CRB_LOOP=0 / 1 forces the stage-split / the persistent form.  A hand-off that does not complete within
  * CRB_LOOP_TIMEOUT_MS (default 2000) makes every workgroup leave; crb_feedback_status reports it. */
 size_t crb_feedback_work_bytes(const crb_plan* plan);
+/* Which form crb_step_rk4_feedback takes for this plan (without a held input): 0 stage-split, 1 fused (gain in LDS), 2 persistent. */
+int crb_feedback_path(const crb_plan* plan);
 /* *status = 0, or (group + 1) of the first hand-off of the last crb_step_rk4_feedback call on `work` that timed out (the
  * state is then unusable).  Synchronises `stream`. */
 int crb_feedback_status(const crb_plan* plan, const void* work, int32_t* status, void* stream);

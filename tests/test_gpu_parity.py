@@ -804,7 +804,9 @@ def test_native_feedback_rollout_entry_point_contract():
     x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
     ens.set_state(x0)
     work = torch.empty((int(lib.crb_feedback_work_bytes(ens.plan.h)),), dtype=torch.uint8, device=ens.device)
-    assert work.numel() == 3 * ens.state.numel() * 8 + ens.state.numel() * 4 + 256
+    # (three state-sized buffers, a force-sized one and the device clock for the stage-split loop; plans the persistent stepper
+    #  covers -- this one: 70 thread-carried nodes -- ask for its buffers when those are larger)
+    assert work.numel() >= 3 * ens.state.numel() * 8 + ens.state.numel() * 4 + 256
     t_end = C.c_double(-1.0)
     vp = lambda t: C.c_void_p(t.data_ptr())
     # bad arguments
