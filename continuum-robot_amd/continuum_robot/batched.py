@@ -260,9 +260,14 @@ class BeamEnsemble:
             nat.check(self._lib.crb_pack_state(self.plan.h, self._ptr(x_red), self._ptr(out), self._stream()))
         return out
 
-    def unpack_state(self, x=None) -> torch.Tensor:
+    def unpack_state(self, x=None, out=None) -> torch.Tensor:
+        """Device layout -> the reference's reduced ordering [B, 2n]; ``out``: a contiguous [B, 2n] tensor to write into (e.g.
+        this rank's slot of an all-gather's result)."""
         x = self.state if x is None else x
-        out = torch.empty((self.n_beams, 2 * self.n), dtype=self.dtype, device=self.device)
+        if out is None:
+            out = torch.empty((self.n_beams, 2 * self.n), dtype=self.dtype, device=self.device)
+        elif tuple(out.shape) != (self.n_beams, 2 * self.n) or out.dtype != self.dtype or not out.is_contiguous():
+            raise ValueError("unpack_state: out must be a contiguous [n_beams, 2n] tensor of the ensemble's dtype")
         with self._on_device():
             nat.check(self._lib.crb_unpack_state(self.plan.h, self._ptr(x), self._ptr(out), self._stream()))
         return out
@@ -306,10 +311,31 @@ class BeamEnsemble:
     def set_state(self, x_red, time: float = 0.0) -> None:
         self.state = self.pack_state(x_red)
         self.time = float(time)
+        self.reset_status()
 
     def zero_state(self) -> None:
         self.state.zero_()
         self.time = 0.0
+        self.reset_status()
+
+    # ------------------------------------------------------------------ per-beam status
+    @property
+    def status(self) -> torch.Tensor:
+        """int32 [B]: 0 while a beam's state is finite, else the number of steps the ensemble had taken at the END of the launch
+        in which the beam went non-finite (fixed-step steppers: step, step_implicit, step_feedback, step_composed's stages).
+        The first access switches the reporting on; `set_state` / `zero_state` / `reset_status` start it afresh.  The
+        reference's solve_ivp just returns NaN rows when its shipped nonlinear element (segments.py:178-208) diverges."""
+        if getattr(self, "_status", None) is None:
+            self._status = torch.zeros((self.n_beams,), dtype=torch.int32, device=self.device)
+            with self._on_device():
+                nat.check(self._lib.crb_plan_set_status(self.plan.h, self._ptr(self._status), 0))
+        return self._status
+
+    def reset_status(self) -> None:
+        if getattr(self, "_status", None) is not None:
+            self._status.zero_()
+            with self._on_device():
+                nat.check(self._lib.crb_plan_set_status(self.plan.h, self._ptr(self._status), 0))
 
     def _impulse(self, desc, keep, impulse_amp, impulse_duration, impulse_index):
         """Fill the impulse part of a crb_input_desc: amplitudes [B] on reduced position index ``impulse_index`` of

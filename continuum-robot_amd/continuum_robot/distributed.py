@@ -89,16 +89,20 @@ def rollout_and_gather(chunks, advance, group=None):
     outs, works, keep = [], [], []
     on = dist.is_initialized()
     world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
     for ens in chunks:
         advance(ens)
-        red = ens.unpack_state().contiguous()
         if on:
-            out = torch.empty((world * red.shape[0],) + tuple(red.shape[1:]), dtype=red.dtype, device=red.device)
-            works.append(dist.all_gather_into_tensor(out, red, group=group, async_op=True))
-            keep.append(red)      # the send buffer must outlive the collective
+            # the layout conversion writes this rank's block straight into its slot of the gathered tensor and the collective
+            # runs in place on it (RCCL recognises the send buffer as that slot: no staging copy of the shard on either side)
+            rows, width, like = ens.n_beams, 2 * ens.n, ens.state
+            out = torch.empty((world * rows, width), dtype=like.dtype, device=like.device)
+            mine = out[rank * rows:(rank + 1) * rows]
+            ens.unpack_state(out=mine)
+            works.append(dist.all_gather_into_tensor(out, mine, group=group, async_op=True))
             outs.append(out)
         else:
-            outs.append(red)
+            outs.append(ens.unpack_state().contiguous())
     for w in works:
         w.wait()                  # the current stream now waits for every exchange
     return outs

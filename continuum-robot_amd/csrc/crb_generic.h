@@ -89,7 +89,22 @@ struct KParams {
     // system scope after the output stores, so that the host can spin on it instead of waiting for the stream
     unsigned long long* done_flag;
     unsigned long long done_seq;
+    // per-beam status (optional): status[b] stays 0 while beam b is finite; the first launch that leaves a non-finite value in
+    // the beam's state writes `status_value` there (the number of steps the ensemble has taken by the end of that launch)
+    int32_t* status;
+    int32_t status_value;
 };
+
+// (end of a stepper launch) a thread whose node came out non-finite marks its beam, once: NaN / Inf never turn finite again,
+// so the first launch that finds them is the launch in which they appeared
+template <typename T>
+__device__ __forceinline__ void mark_nonfinite(const KParams<T>& p, int beam, const T q[3], const T v[3]) {
+    if (!p.status) return;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bad = bad || !isfinite(q[c]) || !isfinite(v[c]);
+    if (bad) atomicCAS(p.status + beam, 0, p.status_value);
+}
 
 enum : int { MODE_STEP = 0, MODE_RHS = 1, MODE_KQ = 2, MODE_STAGE = 3 };
 constexpr int REC_ALL_SLOTS = -2;
@@ -444,6 +459,12 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
                     p.x[xoff + plane + c] = x[3 + c] + dt6 * acc[3 + c];
                 }
             }
+            if (p.stage == 3) {
+                T fq[3], fv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { fq[c] = x[c] + dt6 * acc[c]; fv[c] = x[3 + c] + dt6 * acc[3 + c]; }
+                mark_nonfinite<T>(p, beam, fq, fv);
+            }
         }
         return;
     }
@@ -569,6 +590,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
             p.x[xoff + c] = x[c];
             p.x[xoff + plane + c] = x[3 + c];
         }
+        mark_nonfinite<T>(p, beam, x, x + 3);
     }
 }
 

@@ -519,6 +519,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
             p.x[xoff + c] = xq[c];
             p.x[xoff + plane + c] = xv[c];
         }
+        mark_nonfinite<T>(p, beam, xq, xv);
     }
     // (the next beam's first LDS writes come after barriers that follow this beam's last LDS reads: LOGNW >= 2 the
     //  level-1 exchange, LOGNW == 1 the alternating round-A buffers + the two barriers of the first-stage q exchange)
@@ -762,6 +763,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 oq[c] = (p.stage < 3) ? x0q[c] + cs * sv[c] : x0q[c] + dt6 * nq[c];
                 ov[c] = (p.stage < 3) ? x0v[c] + cs * a[c] : x0v[c] + dt6 * nv[c];
             }
+            if (valid && p.stage == 3) mark_nonfinite<T>(p, beam, oq, ov);
             // (the staging is free again: every thread read its inputs before the barrier of round A)
             if (valid) {
                 at(0, t) = rec4{oq[0], oq[1], oq[2], T(0)}; at(1, t) = rec4{ov[0], ov[1], ov[2], T(0)};
@@ -794,6 +796,7 @@ __global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 
                 strec(p.acc + xoff, nq); strec(p.acc + xoff + plane, nv);
             } else {
                 strec(p.x + xoff, oq); strec(p.x + xoff + plane, ov);
+                mark_nonfinite<T>(p, beam, oq, ov);
             }
         }
         // LOGNW >= 2: the level-1 barrier above orders this beam's round-A reads before the next beam's

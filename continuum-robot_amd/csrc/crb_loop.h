@@ -731,6 +731,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
                             T* dst = p.x + size_t(beam) * 2 * plane + size_t(j + p.off) * 4;
                             *reinterpret_cast<rec4*>(dst) = rec4{oq[0], oq[1], oq[2], T(0)};
                             *reinterpret_cast<rec4*>(dst + plane) = rec4{ov[0], ov[1], ov[2], T(0)};
+                            mark_nonfinite<T>(p, beam, oq, ov);
                         }
                         if (HAS_REF) {
 #pragma unroll

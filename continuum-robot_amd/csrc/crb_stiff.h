@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<
             p.x[xoff + c] = q0[c];
             p.x[xoff + plane + c] = v0[c];
         }
+        mark_nonfinite<T>(p, beam, q0, v0);
     }
 }
 
@@ -374,6 +375,7 @@ __global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb
                 p.x[xoff + c] = q0[c];
                 p.x[xoff + plane + c] = v0[c];
             }
+            mark_nonfinite<T>(p, beam, q0, v0);
         }
         if (LOGNW > 0) __syncthreads();   // the next beam's first q exchange must not overtake this beam's last LDS reads
     }

@@ -109,6 +109,8 @@ struct crb_plan {
     mutable hipEvent_t aux_in = nullptr, aux_out = nullptr;
     mutable hipGraphExec_t step_exec = nullptr;
     mutable std::vector<uint64_t> step_key;
+    mutable int32_t* d_status = nullptr;      // caller's per-beam status words (crb_plan_set_status), or null
+    mutable long long status_steps = 0;       // steps the ensemble has taken since the status buffer was set
     mutable bool loop_used = false;   // the last crb_step_rk4_feedback ran the persistent stepper (its work buffer holds a status word)
 };
 
@@ -698,6 +700,14 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
     delete p;
 }
 
+extern "C" int crb_plan_set_status(const crb_plan* p, void* status, long long steps_done) {
+    if (!p) return fail(CRB_EINVAL, "crb_plan_set_status: null plan");
+    if (steps_done < 0) return fail(CRB_EINVAL, "crb_plan_set_status: steps_done must be >= 0");
+    p->d_status = static_cast<int32_t*>(status);
+    p->status_steps = steps_done;
+    return CRB_OK;
+}
+
 extern "C" int crb_plan_get_layout(const crb_plan* p, crb_layout* o) {
     if (!p || !o) return fail(CRB_EINVAL, "null argument");
     o->dtype = p->dtype;
@@ -819,6 +829,16 @@ KParams<T> base_params(const crb_plan* p) {
     k.gy = T(p->gy);
     k.gvec = static_cast<const T*>(p->d_gvec);
     return k;
+}
+
+// per-beam status of a stepper launch of `n_steps` steps (crb_plan_set_status): what a beam found non-finite at the end of
+// this launch is marked with -- the ensemble's step count by then
+template <typename T>
+void arm_status(const crb_plan* p, KParams<T>& k, int n_steps) {
+    k.status = p->d_status;
+    if (!p->d_status) return;
+    p->status_steps += n_steps;
+    k.status_value = int32_t(p->status_steps < 2147483647LL ? p->status_steps : 2147483647LL);
 }
 
 // dynamic LDS above 64 KiB must be opted into per kernel (the CU has 160 KiB)
@@ -1078,6 +1098,7 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
         k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
         k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+    arm_status(p, k, n_steps);
         k.rec_out = static_cast<double*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
         if (lean_eligible(p, held)) return launch_lean<double>(p, k, st);
         return launch_beam<double, MODE_STEP>(p, k, st);
@@ -1089,6 +1110,7 @@ extern "C" int crb_step_rk4_rec(const crb_plan* p, void* x, double t0, double dt
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
     k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
     k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+    arm_status(p, k, n_steps);
     k.rec_out = static_cast<float*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
     if (lean_eligible(p, held)) return launch_lean<float>(p, k, st);
     return launch_beam<float, MODE_STEP>(p, k, st);
@@ -1339,6 +1361,7 @@ int step_implicit_impl(const crb_plan* p, void* x, double t0, double h, int n_st
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
     k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
     k.t0 = t0; k.dt = h; k.n_steps = n_steps;
+    arm_status(p, k, n_steps);
     k.rec_out = static_cast<T*>(rec_out); k.rec_slot = rec_slot; k.rec_comp = rec_comp; k.rec_every = rec_every; k.rec_n = rec_n;
     StiffParams<T> q;
     q.a_levels = static_cast<const T*>(p->d_alevels);
@@ -1510,6 +1533,7 @@ int fused_feedback_impl(const crb_plan* p, void* x, double t0, double dt, int n_
     KParams<T> k = base_params<T>(p);
     k.x = static_cast<T*>(x);
     k.t0 = t0; k.dt = dt; k.n_steps = n_steps;
+    arm_status(p, k, n_steps);
     k.rec_slot = -1; k.rec_every = 1;
     if (in && in->kind == CRB_INPUT_IMPULSE) {
         k.amp = static_cast<const T*>(in->amp);
@@ -1562,6 +1586,7 @@ extern "C" int crb_step_rk4_feedback(const crb_plan* p, void* x, double t0, doub
         P.k = base_params<double>(p);
         P.k.x = static_cast<double*>(x);
         P.k.t0 = t0; P.k.dt = dt; P.k.n_steps = n_steps;
+        arm_status(p, P.k, n_steps);
         if (in && in->kind == CRB_INPUT_IMPULSE) {
             P.k.amp = static_cast<const double*>(in->amp);
             P.k.imp_slot = in->node - p->off; P.k.imp_dof = in->dof; P.k.duration = in->duration;
@@ -1890,6 +1915,7 @@ static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc,
         k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
         k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
         k.stage = stage; k.t0 = t_stage; k.dt = dt; k.t_dev = t_dev;
+    if (stage == 3) arm_status(p, k, 1);
         if (stage_lean_eligible(p)) return launch_stage_lean<double>(p, k, st);
         return launch_beam<double, MODE_STAGE>(p, k, st);
     }
@@ -1900,6 +1926,7 @@ static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc,
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = duration;
     k.imp_node_b = (in && in->kind == CRB_INPUT_IMPULSE) ? in->node_b : nullptr;
     k.stage = stage; k.t0 = t_stage; k.dt = dt; k.t_dev = t_dev;
+    if (stage == 3) arm_status(p, k, 1);
     if (stage_lean_eligible(p)) return launch_stage_lean<float>(p, k, st);
     return launch_beam<float, MODE_STAGE>(p, k, st);
 }

@@ -235,6 +235,15 @@ int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, 
 int crb_step_implicit(const crb_plan* plan, void* x, double t0, double h, int n_steps, int n_iter,
                       const crb_input_desc* input, const crb_record_desc* rec, double* t_end, void* stream);
 
+/* Per-beam status of the fixed-step steppers (crb_step_rk4[_rec], crb_step_implicit, crb_step_rk4_feedback, crb_rk4_stage at
+ * stage 3).  status: device int32 [B], zeroed by the caller, or NULL to switch the reporting off; steps_done: the number of
+ * steps the ensemble has taken so far.  A launch that leaves a non-finite value in beam b's state writes status[b] = the
+ * ensemble's step count at the END of that launch (once: later launches leave a marked beam alone), so 0 = finite and k > 0 =
+ * "went non-finite within the launch that ended at step k".  The reference has no such report: the shipped nonlinear element
+ * (segments.py:178-208) is linearly unstable for long chains and solve_ivp simply returns NaN rows; this turns that into a
+ * condition the planning layer can read per rollout.  The beams are independent: a diverged beam never affects another. */
+int crb_plan_set_status(const crb_plan* plan, void* status, long long steps_done);
+
 /* Feedback force of a whole ensemble, u = K (r - x) (FullStateLinear.compute_input,
  * control/full_state_linear.py:81; loop of examples/lqr_control.py:95-111), as one MFMA GEMM in the plan's dtype
  * (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32) with the gather from the state layout and the scatter into

@@ -169,8 +169,24 @@ class _FakeChunk:
     def __init__(self, rows):
         self.x = rows.clone()
 
-    def unpack_state(self):
+    # (the part of BeamEnsemble's interface that rollout_and_gather uses)
+    @property
+    def state(self):
         return self.x
+
+    @property
+    def n_beams(self):
+        return self.x.shape[0]
+
+    @property
+    def n(self):
+        return self.x.shape[1] // 2
+
+    def unpack_state(self, out=None):
+        if out is None:
+            return self.x
+        out.copy_(self.x)
+        return out
 
 
 def _worker_chunked(rank, world, port, tmpdir):

@@ -1862,6 +1862,64 @@ def test_full_size_config5_total_on_one_gpu():
         assert_blocks(got[b], want, ens.free_index, 1e-10, what=b)
 
 
+def test_per_beam_status_reports_the_launch_in_which_a_beam_went_non_finite():
+    """crb_plan_set_status / BeamEnsemble.status: 0 while a beam is finite, else the ensemble's step count at the end of the
+    launch that first left a non-finite value in it -- through the lean stepper, the general stepper, the implicit stepper
+    and both closed-loop paths.  (a) poisoned beams are reported by the first launch, their neighbours never;
+    (b) the shipped nonlinear element (segments.py:178-208: no -EA/L u2 coupling) diverges on a 256-element chain past
+    ~1500 steps of dt = 2e-5: every beam is reported in the launch in which torch.isfinite first fails for it."""
+    # (a) lean stepper, packed beams (several per wave) and one beam per workgroup
+    for n_e, B in ((10, 40), (128, 9)):
+        ens = ensemble(nitinol_columns(n_e, "nonlinear"), B, dict(fluid_density=1000.0, enable_fluid=True))
+        st = ens.status
+        x0 = np.zeros((B, 2 * ens.n))
+        x0[3, 5] = np.nan
+        x0[B - 1, ens.n + 1] = np.inf
+        ens.set_state(x0)
+        ens.step(7, 2e-5, impulse_amp=np.full(B, 0.1))
+        ens.step(5, 2e-5, impulse_amp=np.full(B, 0.1))
+        want = np.zeros(B, dtype=np.int32)
+        want[[3, B - 1]] = 7
+        assert np.array_equal(st.cpu().numpy(), want), (n_e, st)
+        fin = torch.isfinite(ens.unpack_state()).all(dim=1).cpu().numpy()
+        assert np.array_equal(fin, want == 0)
+    # general stepper (gravity on a pinned beam), implicit stepper, closed loop (persistent and stage-split)
+    cols = nitinol_columns(70, "linear")
+    for mode in ("general", "implicit", "loop", "split"):
+        kw = dict(enable_gravity=True)
+        c = nitinol_columns(70, "linear", ["PINNED"] + ["NONE"] * 69) if mode == "general" else cols
+        os.environ["CRB_LOOP"] = "1" if mode == "loop" else "0"
+        try:
+            ens = ensemble(c, 66, kw)
+            st = ens.status
+            x0 = np.zeros((66, 2 * ens.n))
+            x0[65, 2] = np.nan
+            ens.set_state(x0)
+            if mode == "general":
+                ens.step(4, 2e-5)
+            elif mode == "implicit":
+                ens.step_implicit(4, 1e-4)
+            else:
+                ens.step_feedback(4, 5e-6, np.zeros((ens.n, 2 * ens.n)))
+            want = np.zeros(66, dtype=np.int32)
+            want[65] = 1 if mode == "split" else 4   # (the stage-split loop is one launch per stage: it reports per step)
+            assert np.array_equal(st.cpu().numpy(), want), (mode, st)
+        finally:
+            os.environ.pop("CRB_LOOP", None)
+    # (b)
+    B = 16
+    ens = ensemble(nitinol_columns(256, "nonlinear"), B, dict(fluid_density=1000.0, enable_fluid=True))
+    st = ens.status
+    amps = 0.1 * (1.0 + np.arange(B) / B)
+    first_bad = np.zeros(B, dtype=np.int64)
+    for launch in range(1, 9):
+        ens.step(500, 2e-5, impulse_amp=amps)
+        fin = torch.isfinite(ens.unpack_state()).all(dim=1).cpu().numpy()
+        first_bad = np.where((first_bad == 0) & ~fin, 500 * launch, first_bad)
+    assert (first_bad > 1000).all() and (first_bad > 0).all(), first_bad   # stable for the metric's 1000 steps, gone by 4000
+    assert np.array_equal(st.cpu().numpy(), first_bad.astype(np.int32))
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """`python bench.py --gpus 2` end to end on this ONE GPU (CRB_BENCH_REHEARSAL=1: both ranks on GPU 0, the exchange
     over gloo): the launcher, the shards, the chunked rollout with its asynchronous all-gather, the max-reduced clock
@@ -1885,6 +1943,28 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert "rehearsal" in line["config"]
     errs = line["check"]["block_err_vs_oracle_last_beam"]
     assert max(errs.values()) < 1e-4, errs          # fp32 against the fp64 oracle at 20 steps
+
+
+def test_bench_takes_the_rccl_path_with_one_rank():
+    """`CRB_BENCH_FORCE_DIST=1 python bench.py --gpus 1`: launcher, torch.distributed over the REAL "nccl" (= RCCL) backend,
+    barrier, the all-gather of the terminal states and the max-reduced clock, with one rank -- the N > 1 code path alive on a
+    one-GPU box (the 2 / 4 / 8-GPU runs are the round-end driver's)."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CRB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CRB_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline", "--repeats", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["ranks_seen"] == 1 and line["config"]["launched_by"] == "bench.py launcher"
+    assert line["config"]["collective"].startswith("all_gather_into_tensor") and "rehearsal" not in line["config"]
+    assert line["config"]["exchange_alone_ms"] > 0
+    assert line["check"]["finite"] and line["check"]["gathered_beams"] == 4096
+    assert max(line["check"]["block_err_vs_oracle_last_beam"].values()) < 1e-9
 
 
 @pytest.mark.parametrize("n_e,B", [(10, 7), (64, 3), (130, 2)])
