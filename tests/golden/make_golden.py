@@ -611,8 +611,224 @@ def g8_long():
     np.savez_compressed(f, **old)
 
 
+# --------------------------------------------------------------------------- G9
+def g9_reference_suite():
+    """Numbers behind the reference's own GPU-dependent tests (tests/README.md maps every one of the 34 to its restated test
+    in tests/test_reference_suite_restated.py): the beams those tests build (their CSV rows are data), SEEDED states in
+    place of their unseeded np.random draws, and what the reference returns on them -- system / input / dynamic-system
+    vectors, registry aggregates, fluid_coefficients, the segment and beam stiffness functions, and the end states of the
+    solve_ivp calls the tests make (RK45 at scipy's defaults over [0, 0.1] s with u = sin(t); rtol 1e-6 over 10 ms)."""
+    from scipy.integrate import solve_ivp
+
+    from continuum_robot.models.abstractions import AbstractForce, AbstractInputHandler
+
+    rng = np.random.default_rng(99)
+    out = {}
+
+    def frame(rows, cols=COLS):
+        return pd.DataFrame({c: [r[i] for r in rows] for i, c in enumerate(cols)})
+
+    def store(prefix, df):
+        for c in df.columns:
+            v = df[c].to_numpy()
+            out[f"{prefix}/{c}"] = v.astype(str) if c in ("type", "boundary_condition") else v.astype(np.float64)
+
+    def csv_of(df):
+        f = tempfile.NamedTemporaryFile(mode="w", delete=False, suffix=".csv")
+        df.to_csv(f, index=False)
+        f.close()
+        return f.name
+
+    bc4 = ["FIXED", "NONE", "NONE", "NONE"]
+    beams = {
+        "t4lin": frame([(0.25, 75e9, 4.91e-10, 6450, 7.85e-5, "linear", bc, 0.001, 0.5) for bc in bc4]),
+        "t4nl": frame([(0.25, 75e9, 4.91e-10, 6450, 7.85e-5, "nonlinear", bc, 0.001, 0.5) for bc in bc4]),
+        "t4fluid": frame([(0.25, 75e9, 4.91e-10, 6450, 7.85e-5, "linear", bc, 0.001, 1.2) for bc in bc4]),
+        "fc4": frame([(0.25, 200e9, 1e-8, 8000, 1e-4, "linear", bc, 1e-4, 1.2) for bc in bc4]),
+        "cx5": frame([(0.2, 200e9, 1e-8, 8000, 1e-4, k, bc, 1e-4, 1.2)
+                      for k, bc in zip(["linear", "linear", "nonlinear", "nonlinear", "nonlinear"], ["FIXED"] + ["NONE"] * 4)]),
+        "mix2": frame([(1.0, 200e9, 1e-6, 7850, 1e-4, k, "NONE") for k in ("linear", "nonlinear")], COLS[:7]),
+        "hyb3": frame([(1.0, 200e9, 1e-6, 7850, 1e-4, k, bc) for k, bc in zip(("linear", "nonlinear", "linear"), ("FIXED", "NONE", "NONE"))],
+                      COLS[:7]),
+    }
+    files = {}
+    for name, df in beams.items():
+        store(name, df)
+        files[name] = csv_of(df)
+
+    class TipSpringDamper(AbstractForce):   # the state-dependent force those tests register: spring + damper on the last w DOF
+        def __init__(self, k, c=10.0):
+            self.k, self.c, self.enabled = k, c, True
+
+        def compute_forces(self, x, t):
+            n = len(x) // 2
+            f = np.zeros(n)
+            f[n - 2] = -self.k * x[n - 2] - self.c * x[n + n - 2]
+            return f
+
+        def is_enabled(self):
+            return self.enabled
+
+    class Gain(AbstractInputHandler):
+        def __init__(self, g):
+            self.g = g
+
+        def compute_input(self, x, u, t):
+            return u * self.g
+
+        def is_enabled(self):
+            return True
+
+    def dyn(name, **fp):
+        b = DynamicEulerBernoulliBeam(files[name], force_params=ForceParams(**fp) if fp else None)
+        b.create_system_func()
+        b.create_input_func()
+        return b
+
+    # ---- test_dynamic_beam.py: system creation, the three solve_ivp tests, fluid_coefficients
+    for name in ("t4lin", "t4nl"):
+        b = dyn(name)
+        n = b.beam_model.M.shape[0]
+        out[f"{name}/dyn_zero_ones"] = b.get_dynamic_system()(0, np.zeros(2 * n), np.ones(n))
+    t0 = time.time()
+    for name, fp in (("t4lin", {}), ("t4nl", {}), ("t4lin", dict(fluid_density=1000.0, enable_fluid_effects=True)),
+                     ("t4nl", dict(fluid_density=1000.0, enable_fluid_effects=True)),
+                     ("t4nl", dict(fluid_density=2000.0, enable_fluid_effects=True))):
+        b = dyn(name, **fp)
+        n = b.beam_model.M.shape[0]
+        f = b.get_dynamic_system()
+        sol = solve_ivp(lambda t, x: f(t, x, np.sin(t) * np.ones(n)), [0, 0.1], np.zeros(2 * n))
+        key = f"{name}/ivp_rho{int(fp.get('fluid_density', 0))}"
+        out[key + "/y_end"] = sol.y[:, -1]
+        out[key + "/nfev"] = np.array(sol.nfev)
+        print(f"g9 {key}: success {sol.success}, nfev {sol.nfev}, {time.time() - t0:.0f} s", flush=True)
+    b = dyn("t4fluid", fluid_density=1000.0, enable_fluid_effects=True)
+    fl = [c for c in b.force_registry.get_registered_forces() if hasattr(c, "fluid_coefficients")][0]
+    for k in ("w_vel_indices", "w_pos_indices", "drag_factors"):
+        out[f"t4fluid/fluid_coefficients/{k}"] = np.asarray(fl.fluid_coefficients[k])
+    ns = len(b.state_to_node_param)
+    out["t4fluid/dyn_ones_zero"] = b.get_dynamic_system()(0.0, np.ones(ns), np.zeros(ns // 2))
+
+    # ---- test_functional_composition.py (beam fc4)
+    n = len(dyn("fc4").state_to_node_param) // 2
+    x = rng.random(2 * n) * 0.01
+    u = rng.random(n) * 0.1
+    out["fc4/x"], out["fc4/u"] = x, u
+    out["fc4/sys_fluid"] = dyn("fc4", fluid_density=1000.0, enable_fluid_effects=True).get_system_func()(x)
+    out["fc4/sys_plain"] = dyn("fc4").get_system_func()(x)
+    out["fc4/sys_plain_big"] = dyn("fc4").get_system_func()(10 * x)
+    out["fc4/sys_gravity_zero"] = dyn("fc4", enable_gravity_effects=True).get_system_func()(np.zeros(2 * n))
+    b = DynamicEulerBernoulliBeam(files["fc4"])
+    spring500 = TipSpringDamper(500.0, 0.0)
+    b.create_system_func(lambda xx, t: spring500.compute_forces(xx, t))
+    tip = np.zeros(2 * n)
+    tip[n - 2] = 0.01
+    out["fc4/sys_spring500"], out["fc4/sys_spring500_tip"] = b.get_system_func()(x), b.get_system_func()(tip)
+    b.create_system_func(lambda xx, t: np.concatenate(([0.0, 100.0 * np.sin(2 * np.pi * t)], np.zeros(len(xx) // 2 - 2))))
+    out["fc4/sys_time_force_zero"] = b.get_system_func()(np.zeros(2 * n))
+    b = dyn("fc4", fluid_density=1000.0, enable_fluid_effects=True, enable_gravity_effects=True)
+    reg = b.force_registry.create_aggregated_function()
+    spring200 = TipSpringDamper(200.0, 0.0)
+    out["fc4/registry_forces"] = reg(x, 0.0)
+    b.create_system_func(lambda xx, t: reg(xx, t) + spring200.compute_forces(xx, t))
+    out["fc4/sys_hybrid"] = b.get_system_func()(x)
+    b = DynamicEulerBernoulliBeam(files["fc4"])
+    b.create_system_func(lambda xx, t: np.concatenate(([0.0, 200.0], np.zeros(len(xx) // 2 - 2))))
+    out["fc4/sys_mock200_zero"] = b.get_system_func()(np.zeros(2 * n))
+    b = dyn("fc4")
+    out["fc4/input_default"] = b.input_func(x, u)
+    out["fc4/input_doubled"] = b.input_func(x, 2.0 * u)
+    b.input_registry.register(Gain(0.1))
+    b.input_registry.register(Gain(0.2))
+    out["fc4/input_aggregated_ones"] = b.input_registry.create_aggregated_function()(x, np.ones(n), 0.0)
+    x0 = rng.random(2 * n) * 0.001
+    f = dyn("fc4").get_dynamic_system()
+    sol = solve_ivp(lambda t, xx: f(t, xx, np.zeros(n)), (0, 0.01), x0, t_eval=np.linspace(0, 0.01, 10), method="RK45", rtol=1e-6)
+    out["fc4/ivp_x0"], out["fc4/ivp_y"] = x0, sol.y
+    print(f"g9 fc4 ivp: success {sol.success}, nfev {sol.nfev}", flush=True)
+
+    # ---- test_advanced_composition.py (beam cx5)
+    n = len(dyn("cx5").state_to_node_param) // 2
+    x = rng.random(2 * n) * 0.01
+    u = rng.random(n) * 0.1
+    out["cx5/x"], out["cx5/u"] = x, u
+    b = dyn("cx5", fluid_density=1000.0, enable_fluid_effects=True, enable_gravity_effects=True)
+    b.force_registry.register(TipSpringDamper(500.0, 5.0))
+    b.create_system_func()
+    out["cx5/sys_fluid_gravity_spring"] = b.get_system_func()(x)
+    b = DynamicEulerBernoulliBeam(files["cx5"])
+    b.force_registry.register(TipSpringDamper(100.0))
+    b.force_registry.register(TipSpringDamper(200.0))
+    b.create_system_func()
+    out["cx5/sys_two_springs"] = b.get_system_func()(x)
+    for scale in (1.0, 2.5):
+        b = DynamicEulerBernoulliBeam(files["cx5"])
+        b.create_system_func(lambda xx, t, s=scale: s * np.concatenate(([0.0, 100.0], np.zeros(len(xx) // 2 - 2))))
+        out[f"cx5/sys_const_force_x{scale}"] = b.get_system_func()(np.zeros(2 * n))
+    b = DynamicEulerBernoulliBeam(files["cx5"])
+    for i in range(50):
+        b.force_registry.register(TipSpringDamper(100.0 + i, 1.0 + 0.1 * i))
+    b.create_system_func()
+    out["cx5/sys_fifty_springs"] = b.get_system_func()(x)
+    b = DynamicEulerBernoulliBeam(files["cx5"])
+    keep = [TipSpringDamper(100.0 + i) for i in range(20)]
+    for fo in keep:
+        b.force_registry.register(fo)
+    for fo in keep[:10]:
+        b.force_registry.unregister(fo)
+    b.create_system_func()
+    out["cx5/sys_ten_of_twenty_springs"] = b.get_system_func()(x)
+    b = DynamicEulerBernoulliBeam(files["cx5"])
+    sp = TipSpringDamper(1000.0)
+    b.force_registry.register(sp)
+    b.create_system_func()
+    b.create_input_func()
+    out["cx5/sys_spring1000"] = b.get_system_func()(x)
+    out["cx5/input_default"] = b.input_func(x, u)
+    sp.enabled = False
+    out["cx5/sys_spring1000_disabled"] = b.get_system_func()(x)
+    small = np.ones(2 * n) * 0.001
+    out["cx5/sys_plain_small_ones"] = dyn("cx5").get_system_func()(small)
+    b = dyn("cx5", fluid_density=1000.0, enable_fluid_effects=True, enable_gravity_effects=True)
+    b.force_registry.register(TipSpringDamper(500.0, 10.0))
+    reg = b.force_registry.create_aggregated_function()
+    b.create_system_func(lambda xx, t: reg(xx, t) + np.concatenate((np.zeros(len(xx) // 2 - 2), [50.0 * np.sin(10.0 * t), 0.0])))
+    xs = 0.1 * x
+    out["cx5/xs"] = xs
+    out["cx5/sys_full"], out["cx5/dyn_full"] = b.get_system_func()(xs), b.get_dynamic_system()(0.1, xs, np.zeros(n))
+    b = dyn("cx5")
+    out["cx5/input_ones"] = b.input_func(x, np.ones(n))
+
+    # ---- test_unified_beam_system.py
+    seg = NonlinearSegment(Properties(length=1.0, elastic_modulus=200e9, moment_inertia=1e-6, density=7850, cross_area=1e-4,
+                                      segment_id=0, element_type="nonlinear"))
+    st6 = np.array([0.01, 0.001, 0.1, 0.02, 0.002, 0.2])
+    out["seg_nl/state"], out["seg_nl/forces"] = st6, seg.get_stiffness_func()(st6)
+    hyb = EulerBernoulliBeam(beams["mix2"][COLS[:6]])
+    nd = hyb.get_mass_matrix().shape[0]
+    q = rng.random(nd) * 0.01
+    out["mix2/q"], out["mix2/beam_stiffness"] = q, hyb.get_stiffness_function()(q)
+    b = dyn("mix2")
+    nd = b.beam_model.get_mass_matrix().shape[0]
+    x = rng.random(2 * nd) * 0.01
+    out["mix2/x"], out["mix2/sys"], out["mix2/dyn"] = x, b.get_system_func()(x), b.get_dynamic_system()(0.0, x, np.zeros(nd))
+    b = dyn("hyb3")
+    nd = b.beam_model.get_mass_matrix().shape[0]
+    x = np.zeros(2 * nd)
+    x[nd:] = 0.01
+    out["hyb3/dyn_initial_velocity"] = b.get_dynamic_system()(0.0, x, np.zeros(nd))
+    out["hyb3/is_hybrid"] = np.array(b.beam_model.is_hybrid())
+
+    np.savez_compressed(os.path.join(HERE, "g9_reference_suite.npz"), **out)
+    for f in files.values():
+        os.unlink(f)
+    print(f"g9: {len(out)} arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g8long"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g8long", "g9"]
+    if "g9" in which:
+        g9_reference_suite()
     if "g8long" in which:
         g8_long()
     if "g8" in which:
