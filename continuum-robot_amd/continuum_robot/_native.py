@@ -126,6 +126,9 @@ def load():
     L.crb_feedback_work_bytes.argtypes = [vp]
     L.crb_feedback_status.argtypes = [vp, vp, C.POINTER(C.c_int32), vp]
     L.crb_feedback_path.argtypes = [vp]
+    L.crb_feedback_force_grouped.argtypes = [vp, vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), vp, vp, vp]
+    L.crb_step_rk4_feedback_grouped.argtypes = [vp, vp, C.c_double, C.c_double, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), vp,
+                                                C.POINTER(InputDesc), vp, C.POINTER(C.c_double), vp]
     L.crb_plan_set_status.argtypes = [vp, vp, C.c_longlong]
     L.crb_feedback_work_bytes.restype = C.c_size_t
     L.crb_step_rk4_feedback.argtypes = [vp, vp, C.c_double, C.c_double, i32, vp, vp, C.POINTER(InputDesc), vp,

@@ -718,7 +718,9 @@ class BeamEnsemble:
         EVERY stage, as examples/lqr_control.py:95-111 does through FullStateLinear.compute_input
         (control/full_state_linear.py:81), plus the optional tip impulse.
 
-        gain       [n, 2n] LQR gain (reduced ordering, e.g. LinearQuadraticRegulator.compute_gain_matrix())
+        gain       [n, 2n] LQR gain (reduced ordering, e.g. LinearQuadraticRegulator.compute_gain_matrix()) for the whole
+                   ensemble, or a list of B matrices (None = no feedback for that beam): one gain per beam of a heterogeneous
+                   ensemble, each in its own beam's reduced ordering; equal gains on like beams run as one group
         reference  [B, 2n] or None (= regulation to 0)
         Stage-split path: per stage one GEMM over the whole ensemble, [B, 2n] x [2n, n] -- the fused
         MFMA kernel crb_feedback_force (gather + GEMM + scatter, in the plan's dtype) -- then one launch
@@ -728,6 +730,8 @@ class BeamEnsemble:
         """
         if t0 is not None:
             self.time = float(t0)
+        if isinstance(gain, (list, tuple)):
+            return self._step_feedback_grouped(n_steps, dt, gain, reference, impulse_amp, impulse_duration, impulse_index)
         K = self._dev(gain, (self.n, 2 * self.n))
         ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
         desc = nat.InputDesc()
@@ -743,6 +747,51 @@ class BeamEnsemble:
                                                       self._ptr(K), self._ptr(ref), C.byref(desc), self._ptr(work),
                                                       C.byref(t_end), self._stream()))
         self._keep = keep + [K, ref, work]
+        self._feedback_work = work
+        self.time = float(t_end.value)
+        return self.time
+
+    def _gain_groups(self, gains):
+        """Per-beam gains -> (group of every beam, one device gain per group): beams with the same free-DOF set and an equal gain
+        matrix form a group (the reference designs one gain per model, lqr_control.py:46-84); None = no feedback for that beam."""
+        if len(gains) != self.n_beams:
+            raise ValueError(f"per-beam gains: expected {self.n_beams} matrices, got {len(gains)}")
+        index, group_of, mats = {}, np.full(self.n_beams, -1, dtype=np.int32), []
+        for b, K in enumerate(gains):
+            if K is None:
+                continue
+            K = np.ascontiguousarray(K, dtype=np.float64)
+            nb = int(self.n_per_beam[b])
+            if K.shape != (nb, 2 * nb):
+                raise ValueError(f"gain of beam {b}: expected shape {(nb, 2 * nb)} (its own reduced state), got {K.shape}")
+            key = (self.free_index_per_beam[b].tobytes(), K.tobytes())
+            if key not in index:
+                index[key] = len(mats)
+                mats.append(torch.as_tensor(K, dtype=self.dtype, device=self.device).contiguous())
+            group_of[b] = index[key]
+        if not mats:
+            raise ValueError("per-beam gains: every entry is None")
+        return group_of, mats
+
+    def _step_feedback_grouped(self, n_steps, dt, gains, reference, impulse_amp, impulse_duration, impulse_index):
+        """step_feedback with one gain per beam (heterogeneous ensembles, `from_dataframes`): grouped by free-DOF set and gain,
+        one MFMA launch per group and stage (crb_step_rk4_feedback_grouped).  `reference`: [B, 2 n_max] padded reduced states."""
+        group_of, mats = self._gain_groups(gains)
+        ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
+        desc = nat.InputDesc()
+        desc.kind = nat.CRB_INPUT_NONE
+        keep = []
+        if impulse_amp is not None:
+            self._impulse(desc, keep, impulse_amp, impulse_duration, impulse_index)
+        ptrs = (C.c_void_p * len(mats))(*[m.data_ptr() for m in mats])
+        work = torch.empty((int(self._lib.crb_feedback_work_bytes(self.plan.h)),), dtype=torch.uint8, device=self.device)
+        t_end = C.c_double(0.0)
+        with self._on_device():
+            nat.check(self._lib.crb_step_rk4_feedback_grouped(
+                self.plan.h, self._ptr(self.state), self.time, float(dt), int(n_steps), len(mats),
+                group_of.ctypes.data_as(C.POINTER(C.c_int32)), ptrs, self._ptr(ref), C.byref(desc), self._ptr(work), C.byref(t_end),
+                self._stream()))
+        self._keep = keep + mats + [ref, work]
         self._feedback_work = work
         self.time = float(t_end.value)
         return self.time

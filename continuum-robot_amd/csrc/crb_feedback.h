@@ -41,7 +41,16 @@ struct FeedbackParams {
     const int32_t* row_off; // [n]  offset of reduced position index i inside a beam's force record
     int B, n, n2;           // n2 = 2n
     size_t x_stride, u_stride;
+    // grouped launches (per-group gains of heterogeneous ensembles, crb_feedback_force_grouped): row m of the product is beam
+    // beam_idx[m] (nullptr: beam m), and the reference rows are the ensemble's padded reduced states [ref_ld] with the
+    // velocities at ref_half (ungrouped: ref_ld = 2n, ref_half = n)
+    const int32_t* beam_idx;
+    int ref_ld, ref_half;
 };
+template <typename T>
+__device__ __forceinline__ int feedback_beam(const FeedbackParams<T>& p, int row) { return p.beam_idx ? p.beam_idx[row] : row; }
+template <typename T>
+__device__ __forceinline__ int feedback_ref_index(const FeedbackParams<T>& p, int k) { return k < p.n ? k : p.ref_half + (k - p.n); }
 // BM x BN outputs per 256-thread workgroup; the 4 waves form a WR x (4/WR) grid, each wave owning
 // (BM/WR) x (BN/WC) outputs = TM x TN MFMA tiles of 16 x 16.  K advances in steps of BK through two LDS
 // stages (one barrier per step).  The global loads of step s+1 are issued BEFORE the MFMAs of step s and
@@ -77,9 +86,9 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
         const int b = m0 + lr + RSTEP * q;
-        const int bc = b < p.B ? b : p.B - 1;
+        const int bc = feedback_beam(p, b < p.B ? b : p.B - 1);
         xrow[q] = p.xs + size_t(bc) * p.x_stride;
-        rrow[q] = HAS_REF ? p.ref + size_t(bc) * p.n2 : nullptr;
+        rrow[q] = HAS_REF ? p.ref + size_t(bc) * p.ref_ld : nullptr;
     }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {
@@ -105,7 +114,7 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             R.xa[q] = xrow[q][coff];
-            if (HAS_REF) R.ra[q] = rrow[q][kc];
+            if (HAS_REF) R.ra[q] = rrow[q][feedback_ref_index(p, kc)];
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) R.gb[q] = grow[q][kc];
@@ -178,8 +187,9 @@ __global__ void __launch_bounds__(256) crb_feedback_kernel(const FeedbackParams<
             const int roff = p.row_off[i];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int beam = m0 + wm + 16 * a + MfmaOps<T>::row(lane, reg);
-                if (beam < p.B) {
+                const int brow = m0 + wm + 16 * a + MfmaOps<T>::row(lane, reg);
+                if (brow < p.B) {
+                    const int beam = feedback_beam(p, brow);
                     const T v = HAS_REF ? acc[a][b][reg] : -acc[a][b][reg];
                     T* dst = p.u + size_t(beam) * p.u_stride + roff;
                     if (gridDim.z > 1) unsafeAtomicAdd(dst, v);
@@ -226,9 +236,9 @@ __global__ void __launch_bounds__(256 + WS_NL) crb_feedback_ws_kernel(const Feed
 #pragma unroll
         for (int q = 0; q < QA; ++q) {
             const int b = m0 + lr + RSTEP * q;
-            const int bc = b < p.B ? b : p.B - 1;
+            const int bc = feedback_beam(p, b < p.B ? b : p.B - 1);
             xrow[q] = p.xs + size_t(bc) * p.x_stride;
-            rrow[q] = HAS_REF ? p.ref + size_t(bc) * p.n2 : nullptr;
+            rrow[q] = HAS_REF ? p.ref + size_t(bc) * p.ref_ld : nullptr;
         }
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
@@ -246,7 +256,7 @@ __global__ void __launch_bounds__(256 + WS_NL) crb_feedback_ws_kernel(const Feed
 #pragma unroll
             for (int q = 0; q < QA; ++q) {
                 R.xa[q] = xrow[q][coff];
-                if (HAS_REF) R.ra[q] = rrow[q][kc];
+                if (HAS_REF) R.ra[q] = rrow[q][feedback_ref_index(p, kc)];
             }
 #pragma unroll
             for (int q = 0; q < QB; ++q) R.gb[q] = grow[q][kc];
@@ -310,8 +320,8 @@ __global__ void __launch_bounds__(256 + WS_NL) crb_feedback_ws_kernel(const Feed
         const int roff = p.row_off[i];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int beam = m0 + 16 * wave + MfmaOps<T>::row(lane, reg);
-            if (beam < p.B) p.u[size_t(beam) * p.u_stride + roff] = HAS_REF ? acc[b][reg] : -acc[b][reg];
+            const int brow = m0 + 16 * wave + MfmaOps<T>::row(lane, reg);
+            if (brow < p.B) p.u[size_t(feedback_beam(p, brow)) * p.u_stride + roff] = HAS_REF ? acc[b][reg] : -acc[b][reg];
         }
     }
 }

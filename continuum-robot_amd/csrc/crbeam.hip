@@ -109,6 +109,10 @@ struct crb_plan {
     mutable hipEvent_t aux_in = nullptr, aux_out = nullptr;
     mutable hipGraphExec_t step_exec = nullptr;
     mutable std::vector<uint64_t> step_key;
+    // crb_feedback_force_grouped: device tables of the last beam -> group assignment (beam lists, reduced -> layout offsets)
+    struct GainGroup { int32_t* beam_idx = nullptr; int32_t* col = nullptr; int32_t* row = nullptr; int n = 0, count = 0; };
+    mutable std::vector<GainGroup> gain_groups;
+    mutable std::vector<int32_t> gain_group_key;
     mutable int32_t* d_status = nullptr;      // caller's per-beam status words (crb_plan_set_status), or null
     mutable long long status_steps = 0;       // steps the ensemble has taken since the status buffer was set
     mutable bool loop_used = false;   // the last crb_step_rk4_feedback ran the persistent stepper (its work buffer holds a status word)
@@ -675,6 +679,9 @@ static int plan_create_impl(crb_plan** out, int device, int dtype, int n_beams, 
     return CRB_OK;
 }
 
+namespace {
+void free_gain_groups(const crb_plan* p);
+}
 extern "C" void crb_plan_destroy(crb_plan* p) {
     if (!p) return;
     if (p->device >= 0) {
@@ -687,6 +694,7 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         (void)hipFree(p->d_levels);
         (void)hipFree(p->d_final);
         (void)hipFree(p->d_free_index);
+        free_gain_groups(p);
         (void)hipFree(p->d_col_off);
         (void)hipFree(p->d_row_off);
         (void)hipFree(p->d_gvec);
@@ -1868,6 +1876,7 @@ int feedback_force_impl(const crb_plan* p, const void* xs, const void* gain, con
     f.B = p->B; f.n = p->n_free; f.n2 = 2 * p->n_free;
     f.x_stride = size_t(2) * p->n_node * 4;
     f.u_stride = size_t(p->n_node) * 4;
+    f.beam_idx = nullptr; f.ref_ld = 2 * p->n_free; f.ref_half = p->n_free;
     const char* force = std::getenv("CRB_FEEDBACK_TILE");
     if (int rc = launch_feedback<T>(force ? std::atoi(force) : 0, f, static_cast<hipStream_t>(stream))) return rc;
     HIP_TRY(hipGetLastError());
@@ -1884,8 +1893,129 @@ extern "C" int crb_feedback_force(const crb_plan* p, const void* xs, const void*
                                : feedback_force_impl<float>(p, xs, gain, ref, u, stream);
 }
 
+namespace {
+void free_gain_groups(const crb_plan* p) {
+    for (auto& g : p->gain_groups) {
+        if (g.beam_idx) (void)hipFree(g.beam_idx);
+        if (g.col) (void)hipFree(g.col);
+        if (g.row) (void)hipFree(g.row);
+    }
+    p->gain_groups.clear();
+    p->gain_group_key.clear();
+}
+// device tables for a beam -> group assignment: per group the list of its beams and the offsets of ITS reduced ordering
+// inside the device layouts (the beams of a group must share the free-DOF set); cached for the assignment last used
+int ensure_gain_groups(const crb_plan* p, int n_groups, const int32_t* beam_group) {
+    std::vector<int32_t> key(beam_group, beam_group + p->B);
+    key.push_back(n_groups);
+    if (key == p->gain_group_key) return CRB_OK;
+    free_gain_groups(p);
+    std::vector<std::vector<int32_t>> members(static_cast<size_t>(n_groups));
+    for (int b = 0; b < p->B; ++b) {
+        const int g = beam_group[b];
+        if (g >= n_groups) return fail(CRB_EINVAL, "crb_feedback_force_grouped: group index out of range");
+        if (g >= 0) members[size_t(g)].push_back(b);
+    }
+    auto free_index_of = [&](int b) -> const std::vector<int32_t>& { return p->beam_free_index.empty() ? p->free_index : p->beam_free_index[size_t(b)]; };
+    p->gain_groups.resize(static_cast<size_t>(n_groups));
+    for (int g = 0; g < n_groups; ++g) {
+        const auto& m = members[size_t(g)];
+        crb_plan::GainGroup& G = p->gain_groups[size_t(g)];
+        G.count = int(m.size());
+        if (m.empty()) continue;
+        const std::vector<int32_t>& fi = free_index_of(m[0]);
+        for (int b : m)
+            if (free_index_of(b) != fi) {
+                free_gain_groups(p);
+                return fail(CRB_EINVAL, "crb_feedback_force_grouped: the beams of a gain group must share one free-DOF set (boundary conditions and length)");
+            }
+        G.n = int(fi.size());
+        std::vector<int32_t> col(size_t(2) * G.n), row(size_t(G.n));
+        for (int r = 0; r < G.n; ++r) {
+            row[r] = (fi[r] / 3) * 4 + (fi[r] % 3);
+            col[r] = row[r];
+            col[G.n + r] = p->n_node * 4 + row[r];
+        }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&G.beam_idx), m.size() * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&G.col), col.size() * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&G.row), row.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(G.beam_idx, m.data(), m.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(G.col, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(G.row, row.data(), row.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    p->gain_group_key = key;
+    return CRB_OK;
+}
+template <typename T>
+int feedback_force_grouped_impl(const crb_plan* p, const void* xs, int n_groups, const void* const* gains, const void* ref, void* u,
+                                void* stream) {
+    for (int g = 0; g < n_groups; ++g) {
+        const crb_plan::GainGroup& G = p->gain_groups[size_t(g)];
+        if (G.count == 0) continue;
+        if (!gains[g]) return fail(CRB_EINVAL, "crb_feedback_force_grouped: null gain for a group that has beams");
+        FeedbackParams<T> f;
+        f.xs = static_cast<const T*>(xs);
+        f.ref = static_cast<const T*>(ref);
+        f.gain = static_cast<const T*>(gains[g]);
+        f.u = static_cast<T*>(u);
+        f.col_off = G.col;
+        f.row_off = G.row;
+        f.B = G.count; f.n = G.n; f.n2 = 2 * G.n;
+        f.x_stride = size_t(2) * p->n_node * 4;
+        f.u_stride = size_t(p->n_node) * 4;
+        f.beam_idx = G.beam_idx; f.ref_ld = 2 * p->n_free; f.ref_half = p->n_free;
+        const char* force = std::getenv("CRB_FEEDBACK_TILE");
+        if (int rc = launch_feedback<T>(force ? std::atoi(force) : 0, f, static_cast<hipStream_t>(stream))) return rc;
+        HIP_TRY(hipGetLastError());
+    }
+    return CRB_OK;
+}
+}  // namespace
+
+extern "C" int crb_feedback_force_grouped(const crb_plan* p, const void* xs, int n_groups, const int32_t* beam_group,
+                                          const void* const* gains, const void* ref, void* u, void* stream) {
+    if (int rc = need_device(p, "crb_feedback_force_grouped")) return rc;
+    if (!xs || !u || !beam_group || !gains || n_groups < 1) return fail(CRB_EINVAL, "crb_feedback_force_grouped: null pointer or no group");
+    if (int rc = ensure_gain_groups(p, n_groups, beam_group)) return rc;
+    return p->dtype == CRB_F64 ? feedback_force_grouped_impl<double>(p, xs, n_groups, gains, ref, u, stream)
+                               : feedback_force_grouped_impl<float>(p, xs, n_groups, gains, ref, u, stream);
+}
+
 static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage, int stage,
                          double t_stage, const double* t_dev, double dt, const crb_input_desc* in, void* stream);
+
+extern "C" int crb_step_rk4_feedback_grouped(const crb_plan* p, void* x, double t0, double dt, int n_steps, int n_groups,
+                                             const int32_t* beam_group, const void* const* gains, const void* ref,
+                                             const crb_input_desc* in, void* work, double* t_end, void* stream) {
+    if (int rc = need_device(p, "crb_step_rk4_feedback_grouped")) return rc;
+    if (!x || !work || !beam_group || !gains || n_groups < 1) return fail(CRB_EINVAL, "crb_step_rk4_feedback_grouped: null pointer or no group");
+    if (n_steps < 0 || !(dt > 0)) return fail(CRB_EINVAL, "crb_step_rk4_feedback_grouped: n_steps >= 0 and dt > 0 required");
+    if (int rc = ensure_gain_groups(p, n_groups, beam_group)) return rc;
+    p->loop_used = false;
+    const size_t state = size_t(p->B) * 2 * p->n_node * 4 * (p->dtype == CRB_F64 ? sizeof(double) : sizeof(float));
+    char* w = static_cast<char*>(work);
+    void* acc = w;
+    void* bufs[2] = {w + state, w + 2 * state};
+    void* u = w + 3 * state;
+    // entries of u that no group writes (constrained DOFs, beams without a gain) must read as zero
+    HIP_TRY(hipMemsetAsync(u, 0, state / 2, static_cast<hipStream_t>(stream)));
+    double t = t0;
+    for (int s = 0; s < n_steps; ++s) {
+        const double th = t + 0.5 * dt, t1 = t + dt;   // same clock convention as crb_step_rk4
+        const double ts[4] = {t, th, th, t1};
+        const void* cur = x;
+        for (int stage = 0; stage < 4; ++stage) {
+            if (int rc = crb_feedback_force_grouped(p, cur, n_groups, beam_group, gains, ref, u, stream)) return rc;
+            void* nxt = bufs[stage & 1];
+            if (int rc = rk4_stage_impl(p, x, cur, acc, nxt, u, stage, ts[stage], nullptr, dt, in, stream)) return rc;
+            cur = nxt;
+        }
+        t = t + dt;
+    }
+    if (t_end) *t_end = t;
+    return CRB_OK;
+}
+
 extern "C" int crb_rk4_stage(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage,
                              int stage, double t_stage, double dt, const crb_input_desc* in, void* stream) {
     return rk4_stage_impl(p, x, xs, acc, xs_next, u_stage, stage, t_stage, nullptr, dt, in, stream);

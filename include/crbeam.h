@@ -135,7 +135,8 @@ int crb_plan_create(crb_plan** out, int device, int dtype, int n_beams, const cr
  * CRB_CORRECTED_AXIAL must be common.  Assembly and factorisation run batched on the device (one workgroup per beam).
  * When the beams' free-DOF sets differ (crb_layout.mixed_topology) the reduced vectors of crb_pack_* / crb_unpack_*
  * are [B][rows][n_free] with n_free the ensemble's maximum: beam b uses the first n_free_b entries of each row, the
- * rest is ignored on pack and zero on unpack; crb_feedback_force (one gain for the whole ensemble) is not available.
+ * rest is ignored on pack and zero on unpack; crb_feedback_force (one gain for the whole ensemble) is not available --
+ * crb_feedback_force_grouped takes one gain per group of like beams.
  * The host inspectors (crb_plan_get_free_index/_mass/_stiffness/_pcr_tables/_slot_tables) describe beam 0. */
 int crb_plan_create_ensemble(crb_plan** out, int device, int dtype, int n_beams, const crb_beam_desc* descs);
 /* n_elem and n_free (size of the reference's reduced position vector) of one beam of the plan; either may be NULL */
@@ -252,6 +253,20 @@ int crb_plan_set_status(const crb_plan* plan, void* status, long long steps_done
  *   ref  device [B][2n] reduced or NULL=0   u     device [B][n_node][4]: free-DOF entries are
  *                                                  overwritten, the rest must already be zero */
 int crb_feedback_force(const crb_plan* plan, const void* xs, const void* gain, const void* ref, void* u, void* stream);
+
+/* The same for heterogeneous ensembles (crb_plan_create_ensemble; SURVEY f-3): one gain per GROUP of beams, as the reference
+ * designs one gain per model (examples/lqr_control.py:46-84, control/linear_quadratic_regulator.py:84-191).
+ *   beam_group  host int32 [B]: the group of every beam, or -1 (no feedback: its u stays 0)
+ *   gains       host array of n_groups device pointers, gains[g] = [n_g][2 n_g] row-major in the reduced ordering of group g's
+ *               beams, which must share one free-DOF set (n_g = their n_free)
+ *   ref         device [B][2 n_free] padded reduced states as crb_pack_state takes them, or NULL
+ * One MFMA launch per group (rows gathered through the group's beam list); u must be zero where no group writes. */
+int crb_feedback_force_grouped(const crb_plan* plan, const void* xs, int n_groups, const int32_t* beam_group,
+                               const void* const* gains, const void* ref, void* u, void* stream);
+/* crb_step_rk4_feedback with per-group gains: the stage-split loop (grouped force, then crb_rk4_stage, per stage). */
+int crb_step_rk4_feedback_grouped(const crb_plan* plan, void* x, double t0, double dt, int n_steps, int n_groups,
+                                  const int32_t* beam_group, const void* const* gains, const void* ref,
+                                  const crb_input_desc* input, void* work, double* t_end, void* stream);
 
 /* ONE stage of the stage-split RK4 stepper, for inputs that change from stage to stage -- state
  * feedback u = K(r - x) evaluated inside the RHS as examples/lqr_control.py:95-111 does

@@ -1103,6 +1103,76 @@ def test_reference_parallel_examples_run_as_one_ensemble():
             assert_blocks(xd[b], ob.rhs(x[b]), ens.free_index, 1e-10, what=b)
 
 
+def _lqr_gain_of(cols, node_bc=None):
+    """The gain lqr_control.py:46-84 designs for ONE model: CARE on the beam's LINEAR model (every element taken as linear --
+    a nonlinear element has no stiffness matrix, euler_bernoulli_beam.py:422-511), Q = diag(100 I, 10 I), R = I."""
+    from continuum_robot import _native as nat
+    from continuum_robot.control import LinearQuadraticRegulator
+
+    lin = dict(cols)
+    lin["type"] = np.array(["linear"] * len(cols["length"]))
+    plan = nat.Plan(lin, node_bc=node_bc, device=-1)
+    K, M = plan.stiffness(), plan.mass()
+    n = K.shape[0]
+    Q = np.eye(2 * n)
+    Q[:n, :n] *= 100
+    Q[n:, n:] *= 10
+    return LinearQuadraticRegulator(K, M, Q, np.eye(n)).compute_gain_matrix()
+
+
+def test_per_beam_gains_close_the_loop_on_heterogeneous_ensembles():
+    """crb_step_rk4_feedback_grouped / step_feedback(gain=[K_b ...]): one LQR gain per model, as the reference designs them
+    (lqr_control.py:46-84).  (a) The six tasks of examples/beam_comparison_fluid.py:52-76 as one ensemble, each beam under the
+    CARE gain of its own linearised model (three distinct gains, each shared by the dry and the wet task: three groups);
+    (b) an ensemble whose beams differ in length and boundary conditions (mixed topology: per-beam reduced orderings, padded
+    references), one beam without any feedback.  Every beam against RK4 over ITS oracle RHS with ITS gain in every stage."""
+    from continuum_robot.batched import BeamEnsemble
+    from continuum_robot.models.force_params import ForceParams
+
+    files = _example_files()
+    none, fluid = ForceParams(), ForceParams(fluid_density=1000.0, enable_fluid_effects=True)
+    tasks = [("linear", none), ("nonlinear", none), ("mixed", none), ("linear", fluid), ("nonlinear", fluid), ("mixed", fluid)]
+    ens = BeamEnsemble.from_dataframes([files[k] for k, _ in tasks], force_params=[fp for _, fp in tasks])
+    gain_of = {k: _lqr_gain_of(files[k]) for k in files}
+    gains = [gain_of[k] for k, _ in tasks]
+    B, steps, dt = len(tasks), 300, 5e-6
+    amps = 0.1 * (1.0 + np.arange(B))
+    ens.step_feedback(steps, dt, gains, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    for b, (k, fp) in enumerate(tasks):
+        ob = oracle_beam(files[k], fluid_density=fp.fluid_density, enable_fluid=fp.enable_fluid_effects)
+        want = ob.rk4_feedback(np.zeros(2 * ob.n), dt, steps, gains[b], amp=amps[b])
+        assert np.isfinite(want).all() and np.abs(want).max() > 0
+        assert_blocks(got[b], want, ens.free_index, 1e-9, what=(k, fp.enable_fluid_effects))
+    # (b) lengths, boundary conditions and gravity differ; references; beam 2 uncontrolled
+    rng = np.random.default_rng(21)
+    ne = [6, 4, 6, 5, 4, 6]
+    bcs_of = [["FIXED"] + ["NONE"] * 5, ["PINNED"] + ["NONE"] * 3, ["FIXED"] + ["NONE"] * 5, ["FIXED", "NONE", "PINNED", "NONE", "NONE"],
+              ["PINNED"] + ["NONE"] * 3, ["FIXED"] + ["NONE"] * 5]
+    beams = [nitinol_columns(n, "linear", bc) for n, bc in zip(ne, bcs_of)]
+    fps = [ForceParams(enable_gravity_effects=bool(b % 2)) for b in range(len(ne))]
+    ens = BeamEnsemble.from_dataframes(beams, force_params=fps)
+    assert ens.mixed_topology
+    B = len(ne)
+    gains = [_lqr_gain_of(beams[b]) for b in range(B)]
+    gains[2] = None
+    obs = [oracle_beam(beams[b], enable_gravity=fps[b].enable_gravity_effects) for b in range(B)]
+    x0 = [rng.normal(0.0, 1e-5, 2 * ob.n) for ob in obs]
+    refs = [rng.normal(0.0, 1e-4, 2 * ob.n) for ob in obs]
+    ens.set_state(ens.pad_states(x0))
+    steps = 120
+    ens.step_feedback(steps, dt, gains, reference=ens.pad_states(refs), impulse_amp=np.full(B, 0.05), impulse_index=-2)
+    for b in range(B):
+        K = gains[b] if gains[b] is not None else np.zeros((obs[b].n, 2 * obs[b].n))
+        want = obs[b].rk4_feedback(x0[b], dt, steps, K, reference=refs[b], amp=0.05)
+        assert_blocks(ens.beam_state(b), want, obs[b].red2full(), 1e-9, what=("mixed", b))
+    # like models under equal gains share a group: {0, 5}, {1, 4}, {3}; beam 2 has none
+    group_of, mats = ens._gain_groups(gains)
+    assert group_of[0] == group_of[5] and group_of[1] == group_of[4] and group_of[2] == -1 and len(mats) == 3
+    with pytest.raises(ValueError, match="expected shape"):
+        ens.step_feedback(1, dt, [gains[0]] * B)
+
+
 @pytest.mark.parametrize("size", ["small", "lean"])
 def test_ensemble_with_per_beam_lengths_boundary_conditions_and_force_params(size):
     """One ensemble of beams that differ in element COUNT (padding nodes), boundary-condition column (FIXED / PINNED /
