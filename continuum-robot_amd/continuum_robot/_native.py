@@ -64,6 +64,11 @@ class RecordDesc(C.Structure):
     _fields_ = [("plane", C.c_int32), ("node", C.c_int32), ("dof", C.c_int32), ("every", C.c_int32), ("out", C.c_void_p)]
 
 
+class ControlDesc(C.Structure):
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("first_rate", C.c_double), ("positions_only", C.c_int32),
+                ("n_iter", C.c_int32), ("max_rungs", C.c_int32), ("reserved", C.c_int32)]
+
+
 class NativeError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"libcrbeam error {code}: {message}")
@@ -122,6 +127,8 @@ def load():
     L.crb_feedback_force.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crb_step_implicit.argtypes = [vp, vp, C.c_double, C.c_double, i32, i32, C.POINTER(InputDesc),
                                     C.POINTER(RecordDesc), C.POINTER(C.c_double), vp]
+    L.crb_solve_controlled.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(ControlDesc), C.POINTER(InputDesc), vp, vp,
+                                       vp, vp, vp, vp]
     L.crb_rk4_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.POINTER(InputDesc), vp]
     L.crb_feedback_work_bytes.argtypes = [vp]
     L.crb_feedback_status.argtypes = [vp, vp, C.POINTER(C.c_int32), vp]

@@ -477,7 +477,8 @@ class BeamEnsemble:
 
     def solve_ivp(self, t_span, t_eval, method: str = "LSODA", impulse_amp=None, impulse_duration: float = 0.01,
                   impulse_index: int = -2, held_force=None, substeps: Union[int, str, None] = None,
-                  rtol: float = 1e-3, atol: float = 1e-6, control: str = "all", gain=None, reference=None):
+                  rtol: float = 1e-3, atol: float = 1e-6, control: str = "all", gain=None, reference=None,
+                  controller: str = "auto"):
         """The examples' integration call for the whole ensemble (examples/example_utilities.py:153-159:
         ``solve_ivp(f, t_span, x0, method="LSODA", t_eval=np.arange(t0, t1, DT))``) from the RESIDENT state, with the
         examples' forcing.  ``t_eval`` must be a uniform grid starting at ``t_span[0]`` (what ``np.arange`` gives).
@@ -499,6 +500,11 @@ class BeamEnsemble:
                  every method except "RK45"; the stiff methods choose its step by ``rtol`` / ``atol`` with the same
                  controller ((fine - coarse) / 15 for the fourth-order scheme; a step beyond RK4's stability limit shows
                  as a failed estimate and is halved), "RK4" takes ``substeps`` as given.
+        controller  where the step-size control of ``substeps="auto"`` runs.  "device": inside the kernel, every beam with its
+                 own step sequence, the whole span in ONE launch (``solve_controlled`` / crb_solve_controlled; the closed loop
+                 only for gains that fit the LDS, beams of up to ~30 elements);  "host": the same controller as a host loop
+                 over fixed-step launches, the worst beam deciding for the ensemble (``_solve_controlled``; any gain, through
+                 ``step_feedback``);  "auto": the device whenever it can.
         Returns an object with ``t`` [n_t] and ``y`` [B, 2n, n_t] (``y[b]`` is the reference's ``sol.y`` of beam b,
         first column = the state at ``t_span[0]``), ``success``, ``method``; the resident state ends at the last
         ``t_eval`` point reached by whole intervals (RK45: at ``t_span[1]``)."""
@@ -543,6 +549,9 @@ class BeamEnsemble:
             return args
 
         t_switch = None if impulse_amp is None else float(impulse_duration)
+        ctrl_stats = None
+        if controller not in ("auto", "device", "host"):
+            raise ValueError('controller must be "auto", "device" or "host"')
         if n_t == 1:
             ys = first
         elif gain is not None and not isinstance(substeps, str):
@@ -552,6 +561,12 @@ class BeamEnsemble:
                 out.append(self.unpack_state().unsqueeze(0))
             self.time = float(t_span[0]) + (n_t - 1) * dt_eval
             ys = torch.cat(out, dim=0)
+        elif (stiff or gain is not None) and isinstance(substeps, str) and self._device_controller(controller, gain):
+            snaps, stats, per_beam = self.solve_controlled(n_t - 1, dt_eval, rtol=rtol, atol=atol, control=control, gain=gain,
+                                                           reference=reference, t0=float(t_span[0]), **kw)
+            ys = torch.cat([first, self.unpack_snapshots(snaps)], dim=0)
+            used = [int(v) for v in per_beam.max(axis=0)]
+            ctrl_stats = (stats, per_beam)
         elif gain is not None:
             # (RK4 is only conditionally stable: start near the closed loop's limit for the Nitinol examples, 8.6e-6 s)
             ys, used = self._solve_controlled(advance, 4, max(1, int(np.ceil(dt_eval / 5e-6))), float(t_span[0]), dt_eval, n_t,
@@ -584,8 +599,70 @@ class BeamEnsemble:
         sol = OdeResult()
         sol.t, sol.y, sol.success, sol.method = t_eval.copy(), ys.permute(1, 2, 0).contiguous(), True, kind
         if isinstance(substeps, str) and stiff and n_t > 1:
-            sol.substeps = used      # steps per t_eval interval that the controller accepted
+            sol.substeps = used      # steps per t_eval interval that the controller accepted (device: the most any beam took)
+            if ctrl_stats is not None:
+                sol.controller = "device"
+                sol.substeps_per_beam = ctrl_stats[1]        # [B, n_t - 1]
+                sol.doublings = ctrl_stats[0][:, 1].copy()   # repeated pieces per beam
+            else:
+                sol.controller = "host"
         return sol
+
+    def _device_controller(self, controller, gain) -> bool:
+        """Whether ``solve_ivp(substeps="auto")`` runs its controller inside the kernel (crb_solve_controlled's conditions)."""
+        if controller == "host":
+            return False
+        ok = self.dtype == torch.float64 and int(self.plan.layout.threads) <= 256
+        if ok and gain is not None:
+            n2p = (2 * self.n + 7) // 8 * 8
+            lds = 14 * int(self.plan.layout.threads) * 8 + (n2p + n2p * self.n) * 8 + 64
+            ok = not isinstance(gain, (list, tuple)) and not self.mixed_topology and lds <= 160 * 1024
+        if controller == "device" and not ok:
+            raise ValueError("controller=\"device\": fp64 plans with beams of up to 256 thread-carried nodes; the closed loop "
+                             "needs one gain that fits the LDS (beams of up to ~30 elements)")
+        return ok
+
+    def solve_controlled(self, n_intervals: int, dt_eval: float, rtol: float = 1e-3, atol: float = 1e-6, control: str = "all",
+                         gain=None, reference=None, impulse_amp=None, impulse_duration: float = 0.01, impulse_index: int = -2,
+                         held_force=None, t0: Optional[float] = None, n_iter: int = 2, first_rate: float = 0.0,
+                         max_rungs: int = 0, record: bool = True):
+        """``n_intervals`` intervals of length ``dt_eval`` from the resident state with the step size chosen per beam by
+        ``rtol`` / ``atol`` INSIDE the kernel, one launch (crb_solve_controlled, csrc/crb_ctrl.h): the implicit midpoint rule,
+        or -- with ``gain`` -- RK4 with the feedback in every stage.  Returns (snapshots [n_intervals, B, 2, n_node, 4] or
+        None, stats [B, 4] (fine steps accepted, doublings, status, last rung), steps per beam and interval [B, n_intervals]);
+        raises when a beam could not meet the tolerances."""
+        if control not in ("all", "positions"):
+            raise ValueError('control must be "all" or "positions"')
+        if t0 is not None:
+            self.time = float(t0)
+        desc = nat.InputDesc()
+        desc.kind = nat.CRB_INPUT_NONE
+        keep = []
+        if impulse_amp is not None:
+            self._impulse(desc, keep, impulse_amp, impulse_duration, impulse_index)
+        if held_force is not None:
+            held = self.pack_vec(held_force)
+            desc.f_held = held.data_ptr()
+            keep.append(held)
+        K = None if gain is None else self._dev(gain, (self.n, 2 * self.n))
+        ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
+        ctl = nat.ControlDesc(float(rtol), float(atol), float(first_rate), int(control == "positions"), int(n_iter), int(max_rungs), 0)
+        n_intervals = int(n_intervals)
+        snaps = torch.zeros((n_intervals,) + tuple(self.state.shape), dtype=self.dtype, device=self.device) if record else None
+        stats = torch.zeros((self.n_beams, 4), dtype=torch.int32, device=self.device)
+        used = torch.zeros((self.n_beams, max(n_intervals, 1)), dtype=torch.int32, device=self.device)
+        with self._on_device():
+            nat.check(self._lib.crb_solve_controlled(self.plan.h, self._ptr(self.state), self.time, float(dt_eval), n_intervals,
+                                                     C.byref(ctl), C.byref(desc), self._ptr(K), self._ptr(ref), self._ptr(snaps),
+                                                     self._ptr(stats), self._ptr(used), self._stream()))
+        self._keep = keep + [K, ref, snaps, stats, used]
+        st = stats.cpu().numpy()
+        if np.any(st[:, 2] != 0):
+            bad = int(np.flatnonzero(st[:, 2] != 0)[0])
+            raise RuntimeError(f"solve_controlled: the tolerances ask for more steps per interval than the ladder holds "
+                               f"(beam {bad}; {int(np.count_nonzero(st[:, 2]))} beams in all)")
+        self.time = self.time + n_intervals * float(dt_eval)
+        return snaps, st, used.cpu().numpy()[:, :n_intervals]
 
     def _solve_controlled(self, advance, order, m_first, t0, dt_eval, n_t, first, rtol, atol, control, t_switch=None,
                           max_substeps=1 << 14):

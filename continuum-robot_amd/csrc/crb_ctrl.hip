@@ -1,0 +1,60 @@
+// crb_ctrl.hip -- the step-size-controlled steppers (crb_ctrl.h), one translation unit of their own.
+#include "crb_ctrl_launch.h"
+
+namespace crb {
+namespace {
+template <int LV, bool FB, int LNW = -1, bool GRAV = false>
+hipError_t one_controlled(const KParams<double>& k, const CtrlParams<double>& q, int threads, size_t lds, hipStream_t st) {
+    auto kern = crb_controlled_kernel<double, LV, FB, LNW, GRAV>;
+    if (lds > size_t(48) * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(k.B), dim3(threads), lds, st, k, q);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_controlled(const KParams<double>& k, const CtrlParams<double>& q, int levels, bool feedback, int lean_lognw, bool grav,
+                             int threads, size_t lds, hipStream_t st) {
+    if (threads < 64 || threads > 256 || (threads & 63)) return hipErrorInvalidValue;
+#ifdef CRB_FAST_BUILD
+    return hipErrorInvalidValue;
+#else
+    if (lean_lognw >= 0) {   // the lean iteration: all ceil(log2 S) levels of a beam of 2 .. 64 / 65 .. 128 / 129 .. 256 slots
+        if (feedback || threads != (64 << lean_lognw)) return hipErrorInvalidValue;
+#define CRB_CTRL_LEAN(LVV, NWW) \
+        if (levels == LVV && lean_lognw == NWW) \
+            return grav ? one_controlled<LVV, false, NWW, true>(k, q, threads, lds, st) : one_controlled<LVV, false, NWW, false>(k, q, threads, lds, st);
+        CRB_CTRL_LEAN(1, 0) CRB_CTRL_LEAN(2, 0) CRB_CTRL_LEAN(3, 0) CRB_CTRL_LEAN(4, 0) CRB_CTRL_LEAN(5, 0) CRB_CTRL_LEAN(6, 0)
+        CRB_CTRL_LEAN(7, 1) CRB_CTRL_LEAN(8, 2)
+#undef CRB_CTRL_LEAN
+        return hipErrorInvalidValue;
+    }
+    if (feedback) {
+        switch (levels) {
+            case 0: return one_controlled<0, true>(k, q, threads, lds, st);
+            case 1: return one_controlled<1, true>(k, q, threads, lds, st);
+            case 2: return one_controlled<2, true>(k, q, threads, lds, st);
+            case 3: return one_controlled<3, true>(k, q, threads, lds, st);
+            case 4: return one_controlled<4, true>(k, q, threads, lds, st);
+            case 5: return one_controlled<5, true>(k, q, threads, lds, st);
+            case 6: return one_controlled<6, true>(k, q, threads, lds, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    switch (levels) {
+        case 0: return one_controlled<0, false>(k, q, threads, lds, st);
+        case 1: return one_controlled<1, false>(k, q, threads, lds, st);
+        case 2: return one_controlled<2, false>(k, q, threads, lds, st);
+        case 3: return one_controlled<3, false>(k, q, threads, lds, st);
+        case 4: return one_controlled<4, false>(k, q, threads, lds, st);
+        case 5: return one_controlled<5, false>(k, q, threads, lds, st);
+        case 6: return one_controlled<6, false>(k, q, threads, lds, st);
+        case 7: return one_controlled<7, false>(k, q, threads, lds, st);
+        case 8: return one_controlled<8, false>(k, q, threads, lds, st);
+        default: return hipErrorInvalidValue;
+    }
+#endif
+}
+}  // namespace crb

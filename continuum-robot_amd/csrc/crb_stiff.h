@@ -172,6 +172,92 @@ template <typename T>
 __host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) {
     return sizeof(T) * size_t(NT + 1) * size_t(12 + 3 * (lognw > 1 ? lognw - 1 : 0));
 }
+// One modified-Newton iteration of the implicit midpoint step in the lean form: a_m <- Ainv (F(q_m, v_m) + alpha K0 a_m) with
+// q_m = qp + alpha a_m, v_m = v0 + h/2 a_m (qp = q0 + h/2 v0) -- the iteration of crb_implicit_lean_kernel below as a function, for
+// the controlled kernel (crb_ctrl.h).  (The fixed-step kernel keeps its own inlined copy: routing it through this function
+// changes its register allocation -- measured +32 spilled VGPRs in the <6, 0, no gravity, mixed elements> instance.)
+// ldsQ [6][NT+1], ldsA [6][NT+1], ldsB [LOGNW-1][3][NT+1] (used with several waves per beam only).
+template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool PACK>
+__device__ __forceinline__ void lean_implicit_iterate(const ElemCoef<T>& ec, const T (&lin)[5], bool shipped_nl, bool corrected, T dragc,
+                                                      T hm_own, T hm_left, T gx, T gy, const SolveCoef<T, LV>& cf, T* ldsQ, T* ldsA,
+                                                      T* ldsB, int t, int lane, int j, int S, bool valid, bool has_left, bool has_right,
+                                                      int t_l1, int t_r1, int t_r2, const T (&qp)[3], const T (&v0)[3],
+                                                      const T (&uadd)[3], T hh, T alpha, T (&am)[3]) {
+    constexpr int NT = 64 << LOGNW;
+    T qm[3], vm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { qm[c] = qp[c] + alpha * am[c]; vm[c] = v0[c] + hh * am[c]; }
+    // -- one exchange of {q_m, a_m}: the left neighbour's values (and the right neighbour's phi for gravity)
+    T qL[3], zL[3], phiR = T(0);
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            qL[c] = lane_lower<T, 1>(qm[c], lane); zL[c] = lane_lower<T, 1>(am[c], lane);
+            if (PACK) { qL[c] = has_left ? qL[c] : T(0); zL[c] = has_left ? zL[c] : T(0); }
+        }
+        if (GRAV) phiR = lane_higher<T, 1>(qm[2], lane);   // (only used under has_right)
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { ldsQ[size_t(c) * (NT + 1) + t] = qm[c]; ldsQ[size_t(3 + c) * (NT + 1) + t] = am[c]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { qL[c] = ldsQ[size_t(c) * (NT + 1) + t_l1]; zL[c] = ldsQ[size_t(3 + c) * (NT + 1) + t_l1]; }
+        if (GRAV) phiR = ldsQ[size_t(2) * (NT + 1) + t_r1];
+    }
+    T fl[3], fr[3], kl[3], kr[3];
+    if (EM == EM_NONLINEAR) elem_force_nonlinear<T>(ec.c, qL, qm, false, fl, fr);
+    else if (EM == EM_LINEAR) elem_force_linear<T>(ec.c, qL, qm, fl, fr);
+    else elem_force<T>(ec, qL, qm, corrected, fl, fr);
+    elem_force_linear<T>(lin, zL, am, kl, kr);                   // K0 a_m (tangent at q = 0) ...
+    if (EM != EM_LINEAR && shipped_nl) kl[0] = lin[0] * zL[0];    // ... whose shipped-f1 row has no u2 term
+    T pp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { fl[c] -= alpha * kl[c]; fr[c] -= alpha * kr[c]; pp[c] = uadd[c] - fr[c]; }
+    pp[1] += drag_force<T>(dragc, vm[1]);
+    if (GRAV) {
+        T g_own[2], g_left[2];
+        gravity_segment<T>(has_right ? T(0.5) * (qm[2] + phiR) : qm[2], gx, gy, hm_own, g_own);
+        if (LOGNW == 0) {
+            g_left[0] = lane_lower<T, 1>(g_own[0], lane);
+            g_left[1] = lane_lower<T, 1>(g_own[1], lane);
+            if (PACK) { g_left[0] = has_left ? g_left[0] : T(0); g_left[1] = has_left ? g_left[1] : T(0); }
+        } else {
+            gravity_segment<T>(T(0.5) * (qL[2] + qm[2]), gx, gy, hm_left, g_left);
+        }
+        pp[0] += g_own[0] + g_left[0];
+        pp[1] += g_own[1] + g_left[1];
+    }
+    // -- merged round {p, fl} + level 0, then the remaining levels and the final block inverse (of A)
+    T r[3], rlo[3], rhi[3], an[3];
+    if (LOGNW == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const T fl_r1 = lane_higher<T, 1>(fl[c], lane);
+            r[c] = pp[c] - ((!PACK || has_right) ? fl_r1 : T(0));   // (one wave: r first, then ITS neighbours -- see the stepper)
+            rlo[c] = lane_lower<T, 1>(r[c], lane);
+            rhi[c] = lane_higher<T, 1>(r[c], lane);
+            if (PACK) { rlo[c] = has_left ? rlo[c] : T(0); rhi[c] = has_right ? rhi[c] : T(0); }
+        }
+    } else {
+        auto col = [&](int k, int th) -> T& { return ldsA[size_t(k) * (NT + 1) + th]; };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { col(c, t) = pp[c]; col(3 + c, t) = fl[c]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rlo[c] = col(c, t_l1) - fl[c];
+            r[c] = pp[c] - col(3 + c, t_r1);
+            rhi[c] = col(c, t_r1) - col(3 + c, t_r2);
+        }
+    }
+    pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+    lean_reduce_tail<T, LV, LOGNW, PACK>(cf, ldsB, t, lane, j, S, valid, r, an);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) am[c] = an[c];
+    // (LOGNW == 1: round A's columns are rewritten only after the next iteration's q exchange barrier;
+    //  LOGNW >= 2: the level-1 barrier in lean_reduce_tail orders this iteration's reads before the next writes)
+}
+
 // PACK (one-wave form only): beams of fewer than 64 slots, G = 64 / S of them per wave (lane = g S + j), as in the packed
 // explicit stepper: every exchange stays a lane shift, and what a shift drags across a beam boundary is replaced by 0
 // with a select (a diverged wave-mate's Inf / NaN must not reach its neighbours through a 0 * NaN).

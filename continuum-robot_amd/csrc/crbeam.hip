@@ -14,6 +14,7 @@
 #include "crb_kernels.h"
 #include "crb_lean_launch.h"
 #include "crb_loop_launch.h"
+#include "crb_ctrl_launch.h"
 
 using namespace crb;
 
@@ -83,6 +84,13 @@ struct crb_plan {
     static constexpr int N_STIFF_SETS = 4;
     mutable StiffSet stiff_sets[N_STIFF_SETS];
     mutable unsigned long long stiff_clock = 0;
+    // crb_solve_controlled: the table LADDERS of the implicit scheme (A = M + h^2/4 K0 for h = len / 2^r, r < rungs),
+    // one per distinct piece length, the most recently used kept; the piece list of the last call
+    struct Ladder { double len = 0.0; int rungs = 0; void* lev = nullptr; void* fin = nullptr; unsigned long long used = 0; };
+    static constexpr int N_LADDERS = 6;
+    mutable Ladder ladders[N_LADDERS];
+    mutable void* d_pieces = nullptr;
+    mutable size_t pieces_cap = 0;
     // host-vector entry points (crb_rhs_host): full -> reduced map on the device, pinned staging, a stream of the plan's own
     mutable int32_t* d_red_map = nullptr;
     mutable double* h_stage = nullptr;   // pinned + mapped: [2n | n | 2n] doubles (x, u, out)
@@ -700,6 +708,8 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         (void)hipFree(p->d_gvec);
         (void)hipFree(p->d_n_state);
         for (auto& set : p->stiff_sets) { (void)hipFree(set.lev); (void)hipFree(set.fin); }
+        for (auto& lad : p->ladders) { (void)hipFree(lad.lev); (void)hipFree(lad.fin); }
+        (void)hipFree(p->d_pieces);
         (void)hipFree(p->d_red_map);
         if (p->h_stage) (void)hipHostFree(p->h_stage);
         if (p->host_stream) (void)hipStreamDestroy(p->host_stream);
@@ -1430,6 +1440,193 @@ extern "C" int crb_step_implicit(const crb_plan* p, void* x, double t0, double h
     hipStream_t st = static_cast<hipStream_t>(stream);
     return step_implicit_impl<double>(p, x, t0, h, n_steps, n_iter, in, imp_slot, imp_dof, duration, amp, held, rec_out, rec_slot,
                                       rec_comp, rec_every, rec_n, st);
+}
+
+// ------------------------------------------------------------------ step-size control in the kernel (crb_ctrl.h)
+namespace {
+// the ladder of A's tables for pieces of length `len`: rung r holds the factorisation for h = len / 2^r (all levels)
+int ctrl_ladder(const crb_plan* p, double len, int rungs, hipStream_t st, const crb_plan::Ladder** out) {
+    AsmInputs& in = *p->asm_in;
+    const int S = p->S, lf = p->levels_full, nd = in.nd;
+    const size_t lv_rung = size_t(nd) * size_t(lf > 0 ? lf : 1) * S * PCR_LEVEL_VALS, fin_rung = size_t(nd) * S * PCR_FINAL_VALS;
+    crb_plan::Ladder* lad = nullptr;
+    for (auto& c : p->ladders)
+        if (c.lev && c.len == len && c.rungs >= rungs) lad = &c;
+    if (lad) {
+        lad->used = ++p->stiff_clock;
+        *out = lad;
+        return CRB_OK;
+    }
+    lad = &p->ladders[0];
+    for (auto& c : p->ladders)
+        if (c.used < lad->used) lad = &c;
+    if (lv_rung * size_t(rungs) * sizeof(double) > (size_t(8) << 30))
+        return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: the table ladder of this ensemble (per-beam tables) exceeds 8 GiB; give the step count instead");
+    // (work queued on `st` that still reads a replaced ladder is ordered before the frees below: hipFree waits for the device)
+    if (lad->lev) (void)hipFree(lad->lev);
+    if (lad->fin) (void)hipFree(lad->fin);
+    lad->lev = lad->fin = nullptr;
+    lad->len = 0.0; lad->rungs = 0;
+    void *lev = nullptr, *fin = nullptr;
+    const bool ok = hipMalloc(&lev, lv_rung * size_t(rungs) * sizeof(double)) == hipSuccess &&
+                    hipMalloc(&fin, fin_rung * size_t(rungs) * sizeof(double)) == hipSuccess &&
+                    (in.dNormScratch.p || in.dNormScratch.alloc(size_t(lf > 0 ? lf : 1)) == 0);
+    if (!ok) {
+        if (lev) (void)hipFree(lev);
+        if (fin) (void)hipFree(fin);
+        (void)hipGetLastError();
+        return fail(CRB_EHIP, "crb_solve_controlled: device allocation failed");
+    }
+    lad->lev = lev;
+    lad->fin = fin;
+    HIP_TRY(hipMemsetAsync(in.dNormScratch.p, 0, size_t(lf > 0 ? lf : 1) * sizeof(double), st));
+    for (int r = 0; r < rungs; ++r) {
+        const double h = len / double(1 << r);
+        AsmParams a = in.a;
+        a.alpha = 0.25 * h * h;
+        a.slot_out = nullptr; a.lv64 = nullptr; a.fin64_all = nullptr; a.blocks0 = nullptr;
+        a.lvT = static_cast<double*>(lev) + size_t(r) * lv_rung;
+        a.finT = static_cast<double*>(fin) + size_t(r) * fin_rung;
+        a.fin_level = lf;
+        a.norms = in.dNormScratch.p;
+        hipLaunchKernelGGL((crb_assemble_kernel<double>), dim3(nd), dim3(in.threads), in.smem, st, a);
+        HIP_TRY(hipGetLastError());
+    }
+    lad->len = len;
+    lad->rungs = rungs;
+    lad->used = ++p->stiff_clock;
+    *out = lad;
+    return CRB_OK;
+}
+}  // namespace
+
+extern "C" int crb_solve_controlled(const crb_plan* p, void* x, double t0, double dt_eval, int n_intervals,
+                                    const crb_control_desc* ctl, const crb_input_desc* in, const void* gain, const void* ref,
+                                    void* y_out, void* stats, void* used, void* stream) {
+    if (int rc = need_device(p, "crb_solve_controlled")) return rc;
+    if (!x || !ctl || !stats) return fail(CRB_EINVAL, "crb_solve_controlled: null pointer");
+    if (n_intervals < 0 || !(dt_eval > 0)) return fail(CRB_EINVAL, "crb_solve_controlled: n_intervals >= 0 and dt_eval > 0 required");
+    if (!(ctl->rtol > 0) || !(ctl->atol >= 0)) return fail(CRB_EINVAL, "crb_solve_controlled: tolerances must be positive");
+    if (p->dtype != CRB_F64) return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: the controlled steppers need an fp64 plan");
+    if (p->NT > 256) return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: beams of more than 256 thread-carried nodes are not supported");
+    const bool fb = gain != nullptr;
+    const int n_iter = ctl->n_iter > 0 ? ctl->n_iter : 2;
+    const int rungs = ctl->max_rungs > 0 ? ctl->max_rungs : 15;   // up to 2^14 fine steps per piece
+    if (rungs < 2 || rungs > 24) return fail(CRB_EINVAL, "crb_solve_controlled: max_rungs must be in 2 .. 24");
+    if (fb) {
+        if (p->mixed_topology) return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: one gain matrix for the ensemble needs one free-DOF set");
+        if (in && in->f_held) return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: the closed loop runs without a held force");
+        if (p->levels > 6) return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: unsupported number of cyclic-reduction levels");
+        if (ctrl_lds_bytes<double>(p->NT, true, p->n_free) > size_t(160) * 1024)
+            return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: the gain matrix does not fit the LDS (beams of up to ~30 elements); use crb_step_rk4_feedback");
+    } else if (ref) {
+        return fail(CRB_EINVAL, "crb_solve_controlled: a reference without a gain");
+    }
+    int imp_slot = -1, imp_dof = 0;
+    double t_switch = 0.0;
+    bool impulse = false;
+    const void* amp = nullptr;
+    const void* held = nullptr;
+    if (in) {
+        held = in->f_held;
+        if (in->kind == CRB_INPUT_IMPULSE) {
+            if (in->node < 0 || in->node >= p->n_node || in->dof < 0 || in->dof > 2 || !in->amp || !p->any_free[3 * in->node + in->dof])
+                return fail(CRB_EINVAL, "crb_solve_controlled: bad impulse description");
+            imp_slot = in->node - p->off; imp_dof = in->dof; t_switch = in->duration; amp = in->amp;
+            impulse = true;
+        } else if (in->kind != CRB_INPUT_NONE) {
+            return fail(CRB_EINVAL, "crb_solve_controlled: unknown input kind");
+        }
+    }
+    if (n_intervals == 0) return CRB_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    // the pieces: whole t_eval intervals, the one the impulse ends in cut at that instant (inside a piece the input is constant)
+    std::vector<crb::CtrlPiece> pieces;
+    pieces.reserve(size_t(n_intervals) + 1);
+    double lens[crb::CTRL_MAX_LADDERS] = {dt_eval, 0.0, 0.0};
+    int n_ladders = 1;
+    for (int k = 0; k < n_intervals; ++k) {
+        const double t_k = t0 + k * dt_eval, t_n = t0 + (k + 1) * dt_eval;
+        const bool cut = impulse && t_k + 1e-9 * dt_eval < t_switch && t_switch < t_n - 1e-9 * dt_eval;
+        const int parts = cut ? 2 : 1;
+        for (int part = 0; part < parts; ++part) {
+            crb::CtrlPiece c;
+            c.t_a = part == 0 ? t_k : t_switch;
+            const double t_b = (cut && part == 0) ? t_switch : t_n;
+            c.len = cut ? t_b - c.t_a : dt_eval;
+            c.ladder = 0;
+            if (cut) { c.ladder = n_ladders; lens[n_ladders++] = c.len; }
+            c.on = (impulse && 0.5 * (c.t_a + t_b) < t_switch) ? 1 : 0;
+            c.rec = (part == parts - 1 && y_out) ? k : -1;
+            c.interval = k;
+            pieces.push_back(c);
+        }
+    }
+    crb::CtrlParams<double> q;
+    std::memset(&q, 0, sizeof(q));
+    if (!fb) {
+        if (p->levels_full > 8) return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: beams of more than 256 thread-carried nodes are not supported");
+        const int lf = p->levels_full, nd = p->asm_in->nd;
+        for (int l = 0; l < n_ladders; ++l) {
+            const crb_plan::Ladder* lad = nullptr;
+            if (int rc = ctrl_ladder(p, lens[l], rungs, st, &lad)) return rc;
+            q.a_levels[l] = static_cast<const double*>(lad->lev);
+            q.a_final[l] = static_cast<const double*>(lad->fin);
+        }
+        for (int l = n_ladders; l < crb::CTRL_MAX_LADDERS; ++l) { q.a_levels[l] = q.a_levels[0]; q.a_final[l] = q.a_final[0]; }
+        q.lv_rung = size_t(nd) * size_t(lf > 0 ? lf : 1) * p->S * PCR_LEVEL_VALS;
+        q.fin_rung = size_t(nd) * p->S * PCR_FINAL_VALS;
+        q.alv_stride = nd > 1 ? size_t(lf > 0 ? lf : 1) * p->S * PCR_LEVEL_VALS : 0;
+        q.afin_stride = nd > 1 ? size_t(p->S) * PCR_FINAL_VALS : 0;
+    }
+    // (the piece list of an earlier call may still be read by its launch: wait for the stream before replacing it)
+    const size_t piece_bytes = pieces.size() * sizeof(crb::CtrlPiece);
+    HIP_TRY(hipStreamSynchronize(st));
+    if (p->pieces_cap < piece_bytes) {
+        if (p->d_pieces) (void)hipFree(p->d_pieces);
+        p->d_pieces = nullptr; p->pieces_cap = 0;
+        HIP_TRY(hipMalloc(&p->d_pieces, piece_bytes));
+        p->pieces_cap = piece_bytes;
+    }
+    HIP_TRY(hipMemcpy(p->d_pieces, pieces.data(), piece_bytes, hipMemcpyHostToDevice));
+    q.pieces = static_cast<const crb::CtrlPiece*>(p->d_pieces);
+    q.n_pieces = int(pieces.size());
+    q.n_rungs = rungs; q.n_iter = n_iter; q.n_intervals = n_intervals;
+    q.rtol = ctl->rtol; q.atol = ctl->atol;
+    // the first coarse solution: h ~ 1e-4 s for the implicit scheme, 5e-6 s for RK4 (near the closed loop's stability limit
+    // for the Nitinol examples, 8.6e-6 s)
+    q.rate0 = ctl->first_rate > 0 ? ctl->first_rate : (fb ? 2e5 : 1e4);
+    q.n_state = 2 * p->n_free; q.n_state_b = p->d_n_state; q.positions_only = ctl->positions_only ? 1 : 0;
+    q.stats = static_cast<int32_t*>(stats);
+    q.used = static_cast<int32_t*>(used);
+    q.y_out = static_cast<double*>(y_out);
+
+    KParams<double> k = base_params<double>(p);
+    k.G = 1;
+    k.x = static_cast<double*>(x);
+    k.u_held = static_cast<const double*>(held);
+    k.amp = static_cast<const double*>(amp);
+    k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = t_switch;
+    k.imp_node_b = impulse ? in->node_b : nullptr;
+    k.t0 = t0;
+    arm_status(p, k, 0);
+    if (fb) {
+        if (int rc = ensure_red_map(p)) return rc;
+        k.red_map = p->d_red_map;
+        k.n_red = p->n_free;
+        k.fb_gain = static_cast<const double*>(gain);
+        k.fb_ref = static_cast<const double*>(ref);
+    }
+    const int threads = p->NT;
+    // the lean iteration (crb_stiff.h) where the plan allows it: gravity absent or of the plain cantilever's form
+    const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
+    const bool lean = !fb && p->levels_full >= 1 && p->lognw <= 2 && threads == (64 << p->lognw) && (!grav || p->canonical_gravity) &&
+                      std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr;
+    const int lean_lognw = lean ? p->lognw : -1;
+    HIP_TRY(crb::launch_controlled(k, q, fb ? p->levels : p->levels_full, fb, lean_lognw, grav, threads,
+                                   ctrl_lds_bytes<double>(threads, fb, p->n_free, lean_lognw), st));
+    return CRB_OK;
 }
 
 static int rk4_stage_impl(const crb_plan* p, void* x, const void* xs, void* acc, void* xs_next, const void* u_stage, int stage,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRB_VERSION 102
+#define CRB_VERSION 103
 
 enum { CRB_OK = 0, CRB_EINVAL = -1, CRB_EHIP = -2, CRB_ENODEV = -3, CRB_EUNSUPPORTED = -4 };
 enum { CRB_F64 = 0, CRB_F32 = 1 };
@@ -235,6 +235,37 @@ int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, 
  * at second order in h from h ~ 1e-3 s down, velocities only once h resolves the modes they contain. */
 int crb_step_implicit(const crb_plan* plan, void* x, double t0, double h, int n_steps, int n_iter,
                       const crb_input_desc* input, const crb_record_desc* rec, double* t_end, void* stream);
+
+/* The examples' integration call with its TOLERANCES, one launch for the whole span and the whole ensemble:
+ * solve_ivp(f, t_span, x0, method="LSODA", t_eval=np.arange(t0, t1, DT)) at scipy's default rtol 1e-3 / atol 1e-6
+ * (examples/example_utilities.py:153-159) and the closed loop of examples/lqr_control.py:117-125 at rtol 1e-8 / atol 1e-10.
+ * The step size is controlled INSIDE the kernel, per beam (one workgroup per beam; csrc/crb_ctrl.h):
+ *   gain == NULL  the implicit midpoint rule of crb_step_implicit (order 2);
+ *   gain != NULL  RK4 with u = K (ref - x) in every stage (order 4; device [n][2n] / [B][2n] like crb_step_rk4_feedback;
+ *                 beams whose gain fits the LDS, up to ~30 elements; one free-DOF set, no held force).
+ * by step doubling per piece -- a t_eval interval [t0 + k dt_eval, t0 + (k+1) dt_eval], cut at input->duration when the
+ * impulse ends inside it (the impulse is then simply on or off within a piece): m = 2^r and 2m steps from the same state,
+ * (fine - coarse) / (2^order - 1) measured in scipy's norm (RMS over the beam's reduced state -- its position half with
+ * positions_only -- of err / (atol + rtol max(|fine|, |start|))); above 1 or not finite: twice the steps; the fine
+ * solution is the accepted one; far below 1: half the rate for the next piece.  The cyclic-reduction tables of
+ * A = M + (h^2/4) K0 for the whole ladder h = len / 2^r, r < max_rungs, are factorised on the device before the launch (and
+ * kept with the plan).
+ *   y_out  device [n_intervals][B][2][n_node][4] (the state at t0 + (k+1) dt_eval in slot k) or NULL
+ *   stats  device int32 [B][4]: fine steps accepted, doublings, status (0 = reached the end, 2 = a piece asked for more than
+ *          2^(max_rungs-1) steps: the beam stops at the start of that piece), rung of the last piece
+ *   used   device int32 [B][n_intervals] fine steps accepted per interval, or NULL
+ * x ends at t0 + n_intervals dt_eval.  fp64 plans, beams of up to 256 thread-carried nodes. */
+typedef struct crb_control_desc {
+    double rtol, atol;
+    double first_rate;       /* steps per second of the first coarse solution; <= 0: 1e4 (implicit) / 2e5 (closed-loop RK4) */
+    int32_t positions_only;  /* measure the position half of the state only */
+    int32_t n_iter;          /* implicit scheme: modified-Newton iterations per step; <= 0: 2 */
+    int32_t max_rungs;       /* <= 0: 15 */
+    int32_t reserved;
+} crb_control_desc;
+int crb_solve_controlled(const crb_plan* plan, void* x, double t0, double dt_eval, int n_intervals,
+                         const crb_control_desc* control, const crb_input_desc* input, const void* gain, const void* ref,
+                         void* y_out, void* stats, void* used, void* stream);
 
 /* Per-beam status of the fixed-step steppers (crb_step_rk4[_rec], crb_step_implicit, crb_step_rk4_feedback, crb_rk4_stage at
  * stage 3).  status: device int32 [B], zeroed by the caller, or NULL to switch the reporting off; steps_done: the number of
