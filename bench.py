@@ -591,6 +591,29 @@ def worker(args):
             "roofline": roofline,
             "check": check,
         }
+        if cfg.get("implicit") and world == 1 and not args.hetero:
+            # the example's own call on this configuration (examples/example_utilities.py:153-159): 1 s, method="LSODA",
+            # scipy's default tolerances, t_eval every millisecond -- the step size controlled by rtol / atol, once inside
+            # the kernel (ONE launch, crb_solve_controlled) and once by the host loop over fixed-step launches.  Wall times
+            # outside the timed region; the first device run also factorises the table ladder (reported apart).
+            t_eval = np.arange(0.0, 1.0005, 0.001)
+            walls_ivp = {}
+            for ctrl, reps in (("device", 2), ("host", 1)):
+                for rep in range(reps):
+                    e1 = BeamEnsemble(params, Bc, force_params=fp, dtype=dtype, device=f"cuda:{local_rank}") if rep == 0 else e1
+                    e1.zero_state()
+                    torch.cuda.synchronize()
+                    t_a = time.perf_counter()
+                    sol = e1.solve_ivp((0.0, 1.0005), t_eval, method="LSODA", impulse_amp=amps_c[0], controller=ctrl)
+                    torch.cuda.synchronize()
+                    walls_ivp[(ctrl, rep)] = time.perf_counter() - t_a
+                if ctrl == "device":
+                    steps_dev, tip = int(np.sum(sol.substeps_per_beam[0])), float(sol.y[0, e1.n - 2, -1].item())
+            out["solve_ivp_1s_default_tolerances"] = {
+                "wall_s": walls_ivp[("device", 1)], "wall_s_first_call_with_table_ladder": walls_ivp[("device", 0)],
+                "wall_s_host_loop_controller": walls_ivp[("host", 0)], "launches": 1, "fine_steps_accepted": steps_dev,
+                "tip_w_1s": tip, "tip_w_1s_lsoda_tight": -0.41624141,
+                "reference_wall_s": 207.0, "reference_source": "BASELINE.md section 2 (scipy LSODA over the reference RHS, one core)"}
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file) and world == 1 and n_chunks == 1:
             try:
