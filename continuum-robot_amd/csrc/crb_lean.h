@@ -204,6 +204,14 @@ __device__ __forceinline__ void lean_rhs(const ElemCoef<T>& ec, T dragc, bool co
     lean_reduce_tail<T, LV, LOGNW>(cf, ldsB, t, lane, j, S, valid, r, a);
 }
 
+// Waves per SIMD the fp64 lean kernels are register-allocated for.  Two, except single-wave beams with gravity and 5 or
+// more reduction levels: their working set does not fit 256 registers (18 .. 140 spilled VGPRs), and a beam that lives in
+// ONE wave gains nothing from a second resident wave until the ensemble exceeds 1024 beams -- measured, spill-free at one
+// wave per SIMD against two with spills: 1024 x 64 + gravity (BASELINE config 2) 3.27 against 4.13 us per step, 4096 x 64
+// 11.4 against 11.6.  Beams of several waves keep two (their cross-wave exchanges need the second workgroup to hide the
+// barrier latency: 4096 x 128 / x 256 + gravity take 32 / 70 us per step at one wave per SIMD against 21 / 39 at two, spills
+// included).
+__host__ __device__ constexpr int lean_minw_f64(int lv, int lognw, bool grav) { return (grav && lv >= 5 && lognw == 0) ? 1 : 2; }
 // EM (EM_*): the element kind when the whole topology has one; the force evaluation is then straight-line
 // code that the scheduler interleaves with the tail of the previous stage's reduction (measured +8 %
 // over the per-lane branch of EM_MIXED; a wave-uniform run-time branch does not get it).
@@ -217,7 +225,7 @@ template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false, b
 // fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: the headline shape (<= 4 levels, no gravity, no held
 // input) fits 4 waves/SIMD (128 VGPRs; three 8-byte addresses spill, outside the step loop: config 4 runs 8.1e10
 // element-steps/s at 4 waves against 6.6e10 at 3), the other fp32 instantiations keep 3 waves/SIMD (168 VGPRs)
-__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? ((LV <= 4 && !GRAV && !HELD) ? 4 : 3) : 2)
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? ((LV <= 4 && !GRAV && !HELD) ? 4 : 3) : lean_minw_f64(LV, LOGNW, GRAV))
 crb_step_lean_kernel(const KParams<T> p_formal) {
     // The launch parameters are read through the kernarg pointer, which is "laundered" (CRB_FRESH) at the top of
     // every beam and again after the step loop: what the beam prologue / epilogue need (pointers, strides, sizes) is
@@ -549,7 +557,7 @@ __host__ __device__ constexpr size_t stage_lean_lds_bytes(int NT, int lognw) {
     return ((cols + 31) / 32) * 32 + io;
 }
 template <typename T, int LV, int LOGNW, bool GRAV, int EM>
-__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : 2) crb_stage_lean_kernel(const KParams<T> p) {
+__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? 3 : lean_minw_f64(LV, LOGNW, GRAV)) crb_stage_lean_kernel(const KParams<T> p) {
     static_assert(LV >= 1, "lean stage kernel needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char crb_smem[];

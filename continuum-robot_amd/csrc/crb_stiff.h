@@ -167,7 +167,9 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<
 // waves per SIMD the lean implicit kernels are built for: up to 5 levels the tables are no larger than the explicit
 // stepper's (two waves), 6 levels fit as well without the gravity terms (with them: >100 spilled registers), the full
 // 7 / 8 levels of long beams take the register file whole
-__host__ __device__ constexpr int implicit_lean_minw(int lv, bool grav) { return (lv <= 5 || (lv == 6 && !grav)) ? 2 : 1; }
+__host__ __device__ constexpr int implicit_lean_minw(int lv, bool grav, int lognw = 1) {
+    return ((lv <= 5 || (lv == 6 && !grav)) && lean_minw_f64(lv, lognw, grav) == 2) ? 2 : 1;
+}
 template <typename T>
 __host__ __device__ constexpr size_t implicit_lean_lds_bytes(int NT, int lognw) {
     return sizeof(T) * size_t(NT + 1) * size_t(12 + 3 * (lognw > 1 ? lognw - 1 : 0));
@@ -262,7 +264,7 @@ __device__ __forceinline__ void lean_implicit_iterate(const ElemCoef<T>& ec, con
 // explicit stepper: every exchange stays a lane shift, and what a shift drags across a beam boundary is replaced by 0
 // with a select (a diverged wave-mate's Inf / NaN must not reach its neighbours through a 0 * NaN).
 template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool PACK = false>
-__global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV)) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
+__global__ void __launch_bounds__(64 << LOGNW, implicit_lean_minw(LV, GRAV, LOGNW)) crb_implicit_lean_kernel(const KParams<T> p, const StiffParams<T> q) {
     static_assert(LV >= 1, "needs at least one reduction level");
     static_assert(!PACK || LOGNW == 0, "packed beams live inside one wave");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, NULLT = NT;

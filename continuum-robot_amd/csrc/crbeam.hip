@@ -1343,7 +1343,7 @@ int launch_implicit(const crb_plan* p, const KParams<T>& k, const StiffParams<T>
         // one wave per SIMD (the tables of A fill the register file): 256 CUs x 4 / waves per beam workgroups are resident
         int groups = (p->B + p->G - 1) / p->G;
         const bool shared = p->slot_stride == 0 && q.alv_stride == 0 && q.afin_stride == 0;
-        int resident = 256 * 4 / (1 << p->lognw) * implicit_lean_minw(p->stiff_levels, grav);   // (waves per SIMD: crb_stiff.h)
+        int resident = 256 * 4 / (1 << p->lognw) * implicit_lean_minw(p->stiff_levels, grav, p->lognw);   // (waves per SIMD: crb_stiff.h)
         if (const char* env = std::getenv("CRB_LEAN_MAX_GROUPS")) resident = std::atoi(env) > 0 ? std::atoi(env) : resident;   // (tests)
         if (shared && groups > resident) {
             const int rounds = (groups + resident - 1) / resident;
