@@ -127,6 +127,8 @@ def load():
     L.crb_feedback_force.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crb_step_implicit.argtypes = [vp, vp, C.c_double, C.c_double, i32, i32, C.POINTER(InputDesc),
                                     C.POINTER(RecordDesc), C.POINTER(C.c_double), vp]
+    L.crb_step_implicit_damped.argtypes = [vp, vp, C.c_double, C.c_double, i32, i32, C.c_double, C.POINTER(InputDesc),
+                                           C.POINTER(RecordDesc), C.POINTER(C.c_double), vp]
     L.crb_solve_controlled.argtypes = [vp, vp, C.c_double, C.c_double, i32, C.POINTER(ControlDesc), C.POINTER(InputDesc), vp, vp,
                                        vp, vp, vp, vp]
     L.crb_rk4_stage.argtypes = [vp, vp, vp, vp, vp, vp, i32, C.c_double, C.c_double, C.POINTER(InputDesc), vp]

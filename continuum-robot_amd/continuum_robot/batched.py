@@ -434,14 +434,16 @@ class BeamEnsemble:
 
     def step_implicit(self, n_steps: int, h: float, n_iter: int = 2, impulse_amp=None, impulse_duration: float = 0.01,
                       impulse_index: int = -2, held_force=None, t0: Optional[float] = None, record=None,
-                      record_every: int = 1):
+                      record_every: int = 1, rho_inf: float = 1.0):
         """Advance the resident state by ``n_steps`` steps of size ``h`` of the implicit midpoint rule in one launch
         (crb_step_implicit): the stiff end of the reference's call sites -- the examples integrate 1 s with
         ``solve_ivp(method="LSODA")`` (example_utilities.py:153-159) because explicit steppers are limited to
         dt <= ~7e-5 s; here h = 1e-3 ... 1e-4 s is stable.  ``n_iter`` modified-Newton iterations per step (2
         reproduces the converged step); inputs are sampled at the step midpoint.  ``record`` as in ``step``.
         Displacements converge at second order in h; velocity components of modes with |lambda| h >> 1 are not
-        resolved (amplitude kept, phase not)."""
+        resolved (amplitude kept, phase not).  ``rho_inf`` < 1: the numerically damped member of the family
+        (generalised-alpha, crb_step_implicit_damped) -- those modes lose the factor ``rho_inf`` per step instead, as
+        they do under LSODA's BDF formulas; 0 removes them within a step or two, 1 is the midpoint rule."""
         if t0 is not None:
             self.time = float(t0)
         desc = nat.InputDesc()
@@ -468,9 +470,9 @@ class BeamEnsemble:
                                  samples.data_ptr())
             keep.append(samples)
         with self._on_device():
-            nat.check(self._lib.crb_step_implicit(self.plan.h, self._ptr(self.state), self.time, float(h), int(n_steps),
-                                                  int(n_iter), C.byref(desc), C.byref(rec) if rec is not None else None,
-                                                  C.byref(t_end), self._stream()))
+            nat.check(self._lib.crb_step_implicit_damped(self.plan.h, self._ptr(self.state), self.time, float(h), int(n_steps),
+                                                         int(n_iter), float(rho_inf), C.byref(desc),
+                                                         C.byref(rec) if rec is not None else None, C.byref(t_end), self._stream()))
         self._keep = keep
         self.time = t_end.value
         return (self.time, samples) if record is not None else self.time
@@ -478,7 +480,7 @@ class BeamEnsemble:
     def solve_ivp(self, t_span, t_eval, method: str = "LSODA", impulse_amp=None, impulse_duration: float = 0.01,
                   impulse_index: int = -2, held_force=None, substeps: Union[int, str, None] = None,
                   rtol: float = 1e-3, atol: float = 1e-6, control: str = "all", gain=None, reference=None,
-                  controller: str = "auto"):
+                  controller: str = "auto", rho_inf: float = 1.0):
         """The examples' integration call for the whole ensemble (examples/example_utilities.py:153-159:
         ``solve_ivp(f, t_span, x0, method="LSODA", t_eval=np.arange(t0, t1, DT))``) from the RESIDENT state, with the
         examples' forcing.  ``t_eval`` must be a uniform grid starting at ``t_span[0]`` (what ``np.arange`` gives).
@@ -500,6 +502,7 @@ class BeamEnsemble:
                  every method except "RK45"; the stiff methods choose its step by ``rtol`` / ``atol`` with the same
                  controller ((fine - coarse) / 15 for the fourth-order scheme; a step beyond RK4's stability limit shows
                  as a failed estimate and is halved), "RK4" takes ``substeps`` as given.
+        rho_inf  (integer ``substeps`` of the stiff methods) < 1: the damped implicit scheme, see ``step_implicit``.
         controller  where the step-size control of ``substeps="auto"`` runs.  "device": inside the kernel, every beam with its
                  own step sequence, the whole span in ONE launch (``solve_controlled`` / crb_solve_controlled; the closed loop
                  only for gains that fit the LDS, beams of up to ~30 elements);  "host": the same controller as a host loop
@@ -577,7 +580,7 @@ class BeamEnsemble:
                                               first, rtol, atol, control, t_switch)
         elif kind in ("LSODA", "BDF", "RADAU", "IMPLICIT"):
             _, snaps = self.step_implicit((n_t - 1) * int(substeps), dt_eval / int(substeps), record="all",
-                                          record_every=int(substeps), **kw)
+                                          record_every=int(substeps), rho_inf=rho_inf, **kw)
             ys = torch.cat([first, self.unpack_snapshots(snaps)], dim=0)
         elif kind == "RK4":
             if isinstance(substeps, str):

@@ -470,6 +470,10 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
     }
     if (MODE != MODE_STEP) {
         T a[3];
+        if (MODE == MODE_RHS) {   // (the impulse of a stepper's input at t0; amp = 0 without one)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) uh[c] += (c == p.imp_dof && p.t0 < p.duration) ? amp : T(0);
+        }
         stage_accel<T, LV, MODE == MODE_KQ, LEAN>(p, lds, sc, cf, tp, x, x + 3, uh, a);
         if (valid && p.red_map) {
             const size_t rb = size_t(beam) * (MODE == MODE_KQ ? 1 : 2) * size_t(p.n_red);

@@ -266,8 +266,6 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     // LDS positions of the stride-1 / stride-2 neighbours (NULLT outside the beam)
     const int t_l1 = (has_slot && j >= 1) ? thread_of(j - 1) : NULLT;
     const int t_r1 = (has_slot && j + 1 < S) ? thread_of(j + 1) : NULLT;
-    const int t_r2 = (has_slot && j + 2 < S) ? thread_of(j + 2) : NULLT;
-
     if (LOGNW > 0 && t == 0) {  // zero the "no neighbour" slots once
 #pragma unroll
         for (int k = 0; k < RN; ++k) {

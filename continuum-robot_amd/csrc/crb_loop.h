@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256, 1) crb_loop_kernel(const LoopParams<T> P)
     static_assert(sizeof(T) == 8, "the persistent closed-loop stepper is built for fp64 plans");
     typedef typename MfmaOps<T>::acc_t acc4;
     typedef T t2 __attribute__((ext_vector_type(2)));
-    constexpr int SPAD = 16 * NB, NCOL = 3 * SPAD, SPW = 2 * NB, KSW = 3 * SPW, D = LOOP_DEPTH;
+    constexpr int SPAD = 16 * NB, SPW = 2 * NB, KSW = 3 * SPW, D = LOOP_DEPTH;
     constexpr int NTB = 64 << LOGNW, BPP = 256 / NTB, BPW = 64 / NB, NPASS = BPW / BPP, NLI = BPW * NTB;
     static_assert(SPAD == NTB, "one thread per padded slot");
     static_assert(NPASS * BPP == BPW && BPW * NB == 64, "beams of a row block divide evenly");

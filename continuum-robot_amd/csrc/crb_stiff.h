@@ -32,9 +32,16 @@ struct StiffParams {
     size_t alv_stride, afin_stride;
     double h;
     int n_iter;
+    // DAMPED (generalised-alpha with spectral radius rho at infinite frequency; rho = 1 is the midpoint rule above): the
+    // unknown z = (1 - alpha_m) a_{n+1} + alpha_m a_n solves M z = F(q_f, v_f, t_f) with q_f = qp + kappa z, v_f = vp + cv z,
+    //     qp = q_n + c_qv v_n + c_qa a_n,   vp = v_n + c_va a_n,   t_f = t_n + tf_frac h,
+    // by the same iteration with A = M + kappa K0 (the tables above are built for alpha = kappa); then
+    //     a_{n+1} = (z - alpha_m a_n) inv1m,  q_{n+1} = q_n + h v_n + c_q0 a_n + c_q1 a_{n+1},  v_{n+1} = v_n + c_v0 a_n + c_v1 a_{n+1}
+    const T* a0;              // [B][2][n_node][4]: the RHS at t0 (its acceleration plane is a_0)
+    double kappa, cv, c_qv, c_qa, c_va, tf_frac, alpha_m, inv1m, c_q0, c_q1, c_v0, c_v1;
 };
 
-template <typename T, int LV, int MAXT, int MINW>
+template <typename T, int LV, int MAXT, int MINW, bool DAMPED = false>
 __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<T> p, const StiffParams<T> q) {
     const int NT = blockDim.x;
     const Lds<T> lds = carve_lds<T>(NT);
@@ -104,32 +111,50 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_implicit_kernel(const KParams<
         }
         if (p.amp && tp.j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
     }
+    T acc_n[3] = {T(0), T(0), T(0)};   // DAMPED: a_n
+    if (DAMPED && valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { acc_n[c] = q.a0[xoff + plane + c] * sc.mask[c]; am[c] = acc_n[c]; }
+    }
 
-    const T h = T(q.h), hh = T(0.5 * q.h), alpha = T(0.25 * q.h * q.h), alpha2 = T(0.5 * q.h * q.h);
+    const T h = T(q.h), hh = DAMPED ? T(q.cv) : T(0.5 * q.h), alpha = DAMPED ? T(q.kappa) : T(0.25 * q.h * q.h), alpha2 = T(0.5 * q.h * q.h);
     double tc = p.t0;
     for (int step = 0; step < p.n_steps; ++step) {
-        const double tm = __dadd_rn(tc, 0.5 * q.h), t1 = __dadd_rn(tc, q.h);
+        const double tm = __dadd_rn(tc, (DAMPED ? q.tf_frac : 0.5) * q.h), t1 = __dadd_rn(tc, q.h);
         const T av = (tm < p.duration) ? amp : T(0);
-        T uadd[3], qp[3];
+        T uadd[3], qp[3], vp[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             uadd[c] = uh[c] + ((c == p.imp_dof) ? av : T(0));
-            qp[c] = q0[c] + hh * v0[c];
-            am[c] = (step == 0) ? T(0) : am[c];   // starting iterate: the previous step's a_m (0 at the start of a call)
+            if (DAMPED) {
+                qp[c] = q0[c] + T(q.c_qv) * v0[c] + T(q.c_qa) * acc_n[c];
+                vp[c] = v0[c] + T(q.c_va) * acc_n[c];
+            } else {
+                qp[c] = q0[c] + hh * v0[c];
+                vp[c] = v0[c];
+                am[c] = (step == 0) ? T(0) : am[c];   // starting iterate: the previous step's a_m (0 at the start of a call)
+            }
         }
 #pragma unroll 1
         for (int it = 0; it < q.n_iter; ++it) {
             T qm[3], vm[3], an[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { qm[c] = qp[c] + alpha * am[c]; vm[c] = v0[c] + hh * am[c]; }
+            for (int c = 0; c < 3; ++c) { qm[c] = qp[c] + alpha * am[c]; vm[c] = vp[c] + hh * am[c]; }
             stage_accel<T, LV, false, false, true>(p, lds, sc, cf, tp, qm, vm, uadd, an, am, alpha);
 #pragma unroll
             for (int c = 0; c < 3; ++c) am[c] = an[c];
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            q0[c] = q0[c] + h * v0[c] + alpha2 * am[c];
-            v0[c] = v0[c] + h * am[c];
+            if (DAMPED) {
+                const T a1 = (am[c] - T(q.alpha_m) * acc_n[c]) * T(q.inv1m);
+                q0[c] = q0[c] + h * v0[c] + (T(q.c_q0) * acc_n[c] + T(q.c_q1) * a1);
+                v0[c] = v0[c] + (T(q.c_v0) * acc_n[c] + T(q.c_v1) * a1);
+                acc_n[c] = a1;
+            } else {
+                q0[c] = q0[c] + h * v0[c] + alpha2 * am[c];
+                v0[c] = v0[c] + h * am[c];
+            }
         }
         tc = t1;
         if (p.rec_out && valid && (step + 1) % p.rec_every == 0) {   // strided recording, as crb_step_rk4_rec

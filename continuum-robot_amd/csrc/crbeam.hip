@@ -91,6 +91,7 @@ struct crb_plan {
     mutable Ladder ladders[N_LADDERS];
     mutable void* d_pieces = nullptr;
     mutable size_t pieces_cap = 0;
+    mutable void* d_rhs0 = nullptr;      // [B][2][n_node][4]: the RHS at the start of a crb_step_implicit_damped call (its a_0)
     // host-vector entry points (crb_rhs_host): full -> reduced map on the device, pinned staging, a stream of the plan's own
     mutable int32_t* d_red_map = nullptr;
     mutable double* h_stage = nullptr;   // pinned + mapped: [2n | n | 2n] doubles (x, u, out)
@@ -710,6 +711,7 @@ extern "C" void crb_plan_destroy(crb_plan* p) {
         for (auto& set : p->stiff_sets) { (void)hipFree(set.lev); (void)hipFree(set.fin); }
         for (auto& lad : p->ladders) { (void)hipFree(lad.lev); (void)hipFree(lad.fin); }
         (void)hipFree(p->d_pieces);
+        (void)hipFree(p->d_rhs0);
         (void)hipFree(p->d_red_map);
         if (p->h_stage) (void)hipHostFree(p->h_stage);
         if (p->host_stream) (void)hipStreamDestroy(p->host_stream);
@@ -1367,11 +1369,45 @@ int launch_implicit(const crb_plan* p, const KParams<T>& k, const StiffParams<T>
 #endif
 }
 
+// the general implicit kernel in its damped form (generalised-alpha): any level count, one wave per SIMD
+template <typename T, int LV>
+int launch_implicit_damped_lv(const crb_plan* p, const KParams<T>& k, const StiffParams<T>& q, hipStream_t st) {
+    const dim3 grid((p->B + p->G - 1) / p->G), block(p->NT);
+    hipLaunchKernelGGL((crb_implicit_kernel<T, LV, 256, 1, true>), grid, block, lds_bytes<T>(p->NT), st, k, q);
+    HIP_TRY(hipGetLastError());
+    return CRB_OK;
+}
 template <typename T>
-int step_implicit_impl(const crb_plan* p, void* x, double t0, double h, int n_steps, int n_iter, const crb_input_desc* in,
+int launch_implicit_damped(const crb_plan* p, const KParams<T>& k, const StiffParams<T>& q, hipStream_t st) {
+#ifdef CRB_FAST_BUILD
+    return fail(CRB_EUNSUPPORTED, "CRB_FAST_BUILD: implicit stepper not built");
+#else
+    if (p->NT > 256) return fail(CRB_EUNSUPPORTED, "crb_step_implicit: beams of more than 256 thread-carried nodes are not supported");
+    switch (p->stiff_levels) {
+        case 0: return launch_implicit_damped_lv<T, 0>(p, k, q, st);
+        case 1: return launch_implicit_damped_lv<T, 1>(p, k, q, st);
+        case 2: return launch_implicit_damped_lv<T, 2>(p, k, q, st);
+        case 3: return launch_implicit_damped_lv<T, 3>(p, k, q, st);
+        case 4: return launch_implicit_damped_lv<T, 4>(p, k, q, st);
+        case 5: return launch_implicit_damped_lv<T, 5>(p, k, q, st);
+        case 6: return launch_implicit_damped_lv<T, 6>(p, k, q, st);
+        case 7: return launch_implicit_damped_lv<T, 7>(p, k, q, st);
+        case 8: return launch_implicit_damped_lv<T, 8>(p, k, q, st);
+        default: return fail(CRB_EUNSUPPORTED, "crb_step_implicit: beams of more than 256 thread-carried nodes are not supported");
+    }
+#endif
+}
+
+template <typename T>
+int step_implicit_impl(const crb_plan* p, void* x, double t0, double h, int n_steps, int n_iter, double rho, const crb_input_desc* in,
                        int imp_slot, int imp_dof, double duration, const void* amp, const void* held, void* rec_out,
                        int rec_slot, int rec_comp, int rec_every, int rec_n, hipStream_t st) {
-    if (int rc = stiff_tables<T>(p, 0.25 * h * h, st)) return rc;
+    const bool damped = rho < 1.0;
+    // generalised-alpha coefficients (crb_stiff.h: StiffParams); rho = 1 is the midpoint rule with kappa = h^2 / 4
+    const double am_ = (2.0 * rho - 1.0) / (rho + 1.0), af_ = rho / (rho + 1.0);
+    const double gam = 0.5 - am_ + af_, bet = 0.25 * (1.0 - am_ + af_) * (1.0 - am_ + af_);
+    const double kappa = damped ? (1.0 - af_) * bet * h * h / (1.0 - am_) : 0.25 * h * h;
+    if (int rc = stiff_tables<T>(p, kappa, st)) return rc;
     KParams<T> k = base_params<T>(p);
     k.x = static_cast<T*>(x);
     k.u_held = static_cast<const T*>(held);
@@ -1388,13 +1424,40 @@ int step_implicit_impl(const crb_plan* p, void* x, double t0, double h, int n_st
     q.afin_stride = p->asm_in->nd > 1 ? size_t(p->S) * PCR_FINAL_VALS : 0;
     q.h = h;
     q.n_iter = n_iter;
-    return launch_implicit<T>(p, k, q, st);
+    q.a0 = nullptr;
+    if (!damped) return launch_implicit<T>(p, k, q, st);
+    // a_0: the RHS of the state at t0 with the input of t0 (one launch of the RHS kernel into the plan's scratch)
+    if (!p->d_rhs0) HIP_TRY(hipMalloc(&p->d_rhs0, size_t(p->B) * 2 * p->n_node * 4 * sizeof(T)));
+    {
+        KParams<T> r = base_params<T>(p);
+        r.x = static_cast<T*>(x);
+        r.u_held = static_cast<const T*>(held);
+        r.out = static_cast<T*>(p->d_rhs0);
+        r.amp = static_cast<const T*>(amp);
+        r.imp_slot = imp_slot; r.imp_dof = imp_dof; r.duration = duration; r.imp_node_b = k.imp_node_b;
+        r.t0 = t0;
+        if (int rc = launch_beam<T, MODE_RHS>(p, r, st)) return rc;
+    }
+    q.a0 = static_cast<const T*>(p->d_rhs0);
+    const double cv = (1.0 - af_) * gam * h / (1.0 - am_);
+    q.kappa = kappa; q.cv = cv;
+    q.c_qv = (1.0 - af_) * h; q.c_qa = (1.0 - af_) * h * h * (0.5 - bet) - kappa * am_;
+    q.c_va = (1.0 - af_) * h * (1.0 - gam) - cv * am_;
+    q.tf_frac = 1.0 - af_; q.alpha_m = am_; q.inv1m = 1.0 / (1.0 - am_);
+    q.c_q0 = h * h * (0.5 - bet); q.c_q1 = h * h * bet; q.c_v0 = h * (1.0 - gam); q.c_v1 = h * gam;
+    return launch_implicit_damped<T>(p, k, q, st);
 }
 }  // namespace
 
 extern "C" int crb_step_implicit(const crb_plan* p, void* x, double t0, double h, int n_steps, int n_iter,
                                  const crb_input_desc* in, const crb_record_desc* rec, double* t_end, void* stream) {
+    return crb_step_implicit_damped(p, x, t0, h, n_steps, n_iter, 1.0, in, rec, t_end, stream);
+}
+
+extern "C" int crb_step_implicit_damped(const crb_plan* p, void* x, double t0, double h, int n_steps, int n_iter, double rho_inf,
+                                        const crb_input_desc* in, const crb_record_desc* rec, double* t_end, void* stream) {
     if (int rc = need_device(p, "crb_step_implicit")) return rc;
+    if (!(rho_inf >= 0.0 && rho_inf <= 1.0)) return fail(CRB_EINVAL, "crb_step_implicit_damped: rho_inf must be in [0, 1]");
     if (!x) return fail(CRB_EINVAL, "crb_step_implicit: null pointer");
     if (n_steps < 0) return fail(CRB_EINVAL, "crb_step_implicit: n_steps must be >= 0");
     if (!(h > 0)) return fail(CRB_EINVAL, "crb_step_implicit: h must be positive");
@@ -1438,7 +1501,7 @@ extern "C" int crb_step_implicit(const crb_plan* p, void* x, double t0, double h
     }
     if (n_steps == 0) return CRB_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return step_implicit_impl<double>(p, x, t0, h, n_steps, n_iter, in, imp_slot, imp_dof, duration, amp, held, rec_out, rec_slot,
+    return step_implicit_impl<double>(p, x, t0, h, n_steps, n_iter, rho_inf, in, imp_slot, imp_dof, duration, amp, held, rec_out, rec_slot,
                                       rec_comp, rec_every, rec_n, st);
 }
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRB_VERSION 103
+#define CRB_VERSION 104
 
 enum { CRB_OK = 0, CRB_EINVAL = -1, CRB_EHIP = -2, CRB_ENODEV = -3, CRB_EUNSUPPORTED = -4 };
 enum { CRB_F64 = 0, CRB_F32 = 1 };
@@ -235,6 +235,15 @@ int crb_solve_rk45_eval(const crb_plan* plan, void* x, double t0, double t_end, 
  * at second order in h from h ~ 1e-3 s down, velocities only once h resolves the modes they contain. */
 int crb_step_implicit(const crb_plan* plan, void* x, double t0, double h, int n_steps, int n_iter,
                       const crb_input_desc* input, const crb_record_desc* rec, double* t_end, void* stream);
+/* The numerically DAMPED member of the same family: generalised-alpha (Chung & Hulbert) with spectral radius rho_inf in
+ * [0, 1] at infinite frequency -- second order, unconditionally stable, modes with |lambda| h >> 1 lose the factor rho_inf
+ * per step instead of ringing on with the wrong phase (rho_inf = 1: crb_step_implicit exactly; 0: they are gone after one
+ * step).  What LSODA's BDF formulas do to the unresolved modes of the examples' runs (example_utilities.py:153-159) and the
+ * midpoint rule does not.  Same iteration (matrix M + kappa K0, kappa = (1 - alpha_f) beta h^2 / (1 - alpha_m)); the
+ * acceleration history starts from the RHS at t0 (one extra launch per call), the input is sampled at
+ * t + (1 - alpha_f) h.  Runs the general kernel (one wave per SIMD) for every beam shape. */
+int crb_step_implicit_damped(const crb_plan* plan, void* x, double t0, double h, int n_steps, int n_iter, double rho_inf,
+                             const crb_input_desc* input, const crb_record_desc* rec, double* t_end, void* stream);
 
 /* The examples' integration call with its TOLERANCES, one launch for the whole span and the whole ensemble:
  * solve_ivp(f, t_span, x0, method="LSODA", t_eval=np.arange(t0, t1, DT)) at scipy's default rtol 1e-3 / atol 1e-6

@@ -23,6 +23,7 @@
  *   orc_rhs                  dynamic_beam_model.py:256-272, 294-328, 343-362
  *                            xdot = [v ; Minv(-k(q) + f(x, t=0) + u)]
  *   orc_rk4_feedback         the closed loop of examples/lqr_control.py:95-111 (u = K(r-x) per stage)
+ *   orc_implicit_alpha       OURS: the damped member of orc_implicit's family (generalised-alpha, rho at infinity)
  *   orc_implicit             OURS (like the RK4 loop: the reference has no integrator): implicit midpoint rule with
  *                            a modified-Newton iteration, the CPU statement of crb_step_implicit -- the stiff end of
  *                            the solve_ivp(LSODA) call sites (examples/example_utilities.py:153-159); pinned by
@@ -607,6 +608,99 @@ double orc_implicit(const orc_model* m, double* x, double t0, double h, int n_st
         for (int i = 0; i < n; ++i) {
             x[i] = x[i] + h * x[n + i] + 2.0 * alpha * am[i];
             x[n + i] = x[n + i] + h * am[i];
+        }
+        t = t + h;
+    }
+    free(w); free(K0); free(Am);
+    return t;
+}
+
+/* The numerically DAMPED member of the same family: generalised-alpha (Chung & Hulbert 1993) with spectral radius rho
+ * at infinite frequency (rho = 1: the scheme above, no damping; rho = 0: asymptotic annihilation), second order, written
+ * so that the iteration keeps the form of orc_implicit (unknown z = a_{n+1-alpha_m}, constant matrix M + kappa K0):
+ *     alpha_m = (2 rho - 1)/(rho + 1),  alpha_f = rho/(rho + 1),  gamma = 1/2 - alpha_m + alpha_f,  beta = (1 - alpha_m + alpha_f)^2 / 4
+ *     M z = F(q_f, v_f, t_f),   q_f = (1 - alpha_f) q_{n+1} + alpha_f q_n,  v_f likewise,  t_f = t_n + (1 - alpha_f) h,
+ *     z = (1 - alpha_m) a_{n+1} + alpha_m a_n,
+ *     q_{n+1} = q_n + h v_n + h^2 ((1/2 - beta) a_n + beta a_{n+1}),   v_{n+1} = v_n + h ((1 - gamma) a_n + gamma a_{n+1})
+ * i.e. q_f = qp + kappa z, v_f = vp + cv z with kappa = (1 - alpha_f) beta h^2 / (1 - alpha_m), cv = (1 - alpha_f) gamma h / (1 - alpha_m)
+ * and predictors qp, vp that hold the a_n terms.  a_0 = Minv F(q_0, v_0, t_0) (the RHS at the start of the call); the
+ * starting iterate of a step is the previous step's z (a_0 for the first).  OURS: the reference has no integrator; LSODA,
+ * which the examples use (example_utilities.py:153-159), damps unresolved modes through its BDF formulas. */
+double orc_implicit_alpha(const orc_model* m, double* x, double t0, double h, int n_steps, int n_iter, double rho, double amp,
+                          double duration, int idx, const double* u_held) {
+    const int n = m->n_red, nf = m->n_full, N = 2 * n;
+    if (idx < 0) idx += n;
+    const double am_ = (2.0 * rho - 1.0) / (rho + 1.0), af_ = rho / (rho + 1.0);
+    const double gam = 0.5 - am_ + af_, bet = 0.25 * (1.0 - am_ + af_) * (1.0 - am_ + af_);
+    const double kappa = (1.0 - af_) * bet * h * h / (1.0 - am_), cv = (1.0 - af_) * gam * h / (1.0 - am_);
+    const double c_qv = (1.0 - af_) * h, c_qa = (1.0 - af_) * h * h * (0.5 - bet) - kappa * am_;
+    const double c_va = (1.0 - af_) * h * (1.0 - gam) - cv * am_, inv1m = 1.0 / (1.0 - am_);
+    double* Kf = (double*)calloc((size_t)nf * nf, sizeof(double));
+    for (int e = 0; e < m->n_seg; ++e) {
+        double Ke[36];
+        orc_elem_stiff_linear(m->L[e], m->E[e], m->I[e], m->A[e], Ke);
+        if (m->nonlinear[e] && !m->corrected_axial) Ke[0 * 6 + 3] = 0.0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) Kf[(size_t)(3 * e + a) * nf + 3 * e + b] += Ke[a * 6 + b];
+    }
+    double* K0 = (double*)malloc((size_t)n * n * sizeof(double));
+    double* Am = (double*)malloc((size_t)n * n * sizeof(double));
+    orc_mass_dense(m, Am);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            K0[(size_t)i * n + j] = Kf[(size_t)m->red2full[i] * nf + m->red2full[j]];
+            Am[(size_t)i * n + j] += kappa * K0[(size_t)i * n + j];
+        }
+    free(Kf);
+    for (int k = 0; k < n; ++k)
+        for (int i = k + 1; i < n; ++i) {
+            const double f = Am[(size_t)i * n + k] / Am[(size_t)k * n + k];
+            Am[(size_t)i * n + k] = f;
+            if (f != 0.0)
+                for (int j = k + 1; j < n; ++j) Am[(size_t)i * n + j] -= f * Am[(size_t)k * n + j];
+        }
+    double* w = (double*)malloc((size_t)(2 * N + 8 * n) * sizeof(double));
+    double *xm = w, *tmp = w + N, *u = w + 2 * N, *qp = u + n, *vp = qp + n, *z = vp + n, *an = z + n, *g = an + n, *kf = g + n;
+    double t = t0;
+    /* a_0 from the RHS at t0 */
+    for (int i = 0; i < n; ++i) u[i] = u_held ? u_held[i] : 0.0;
+    if (t0 < duration) u[idx] += amp;
+    orc_rhs(m, x, u, tmp);
+    for (int i = 0; i < n; ++i) { an[i] = tmp[n + i]; z[i] = an[i]; }
+    for (int s = 0; s < n_steps; ++s) {
+        const double tf = t + (1.0 - af_) * h;
+        for (int i = 0; i < n; ++i) u[i] = u_held ? u_held[i] : 0.0;
+        if (tf < duration) u[idx] += amp;
+        for (int i = 0; i < n; ++i) {
+            qp[i] = x[i] + c_qv * x[n + i] + c_qa * an[i];
+            vp[i] = x[n + i] + c_va * an[i];
+        }
+        for (int it = 0; it < n_iter; ++it) {
+            for (int i = 0; i < n; ++i) { xm[i] = qp[i] + kappa * z[i]; xm[n + i] = vp[i] + cv * z[i]; }
+            orc_internal_force(m, xm, kf);
+            orc_forces(m, xm, tmp);
+            for (int i = 0; i < n; ++i) {
+                double k0a = 0.0;
+                for (int j = 0; j < n; ++j) k0a += K0[(size_t)i * n + j] * z[j];
+                g[i] = -kf[i] + tmp[i] + u[i] + kappa * k0a;
+            }
+            for (int i = 0; i < n; ++i) {
+                double v = g[i];
+                for (int k = 0; k < i; ++k) v -= Am[(size_t)i * n + k] * g[k];
+                g[i] = v;
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                double v = g[i];
+                for (int k = i + 1; k < n; ++k) v -= Am[(size_t)i * n + k] * g[k];
+                g[i] = v / Am[(size_t)i * n + i];
+            }
+            memcpy(z, g, (size_t)n * sizeof(double));
+        }
+        for (int i = 0; i < n; ++i) {
+            const double a1 = (z[i] - am_ * an[i]) * inv1m;
+            x[i] = x[i] + h * x[n + i] + h * h * ((0.5 - bet) * an[i] + bet * a1);
+            x[n + i] = x[n + i] + h * ((1.0 - gam) * an[i] + gam * a1);
+            an[i] = a1;
         }
         t = t + h;
     }

@@ -54,6 +54,9 @@ def lib():
         L.orc_implicit.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
                                    C.c_double, C.c_int, _dp]
         L.orc_implicit.restype = C.c_double
+        L.orc_implicit_alpha.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double,
+                                         C.c_double, C.c_int, _dp]
+        L.orc_implicit_alpha.restype = C.c_double
         L.orc_rk4_impulse_batch.argtypes = [C.c_void_p, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int,
                                             C.c_double, C.c_int, C.c_int]
         L.orc_rk4_impulse_batch.restype = C.c_int
@@ -213,6 +216,14 @@ class OracleBeam:
         x = _d(x0).copy()
         uu = _d(u_held) if u_held is not None else None
         lib().orc_implicit(self.h, _p(x), t0, h, n_steps, n_iter, amp, duration, idx, _p(uu) if uu is not None else None)
+        return x
+
+    def implicit_alpha(self, x0, h, n_steps, rho, n_iter=3, amp=0.0, duration=0.01, idx=-2, t0=0.0, u_held=None):
+        """Generalised-alpha with spectral radius ``rho`` at infinite frequency (orc_implicit_alpha): the numerically damped
+        member of ``implicit``'s family, the CPU statement of crb_step_implicit_damped; rho = 1 is ``implicit`` up to rounding."""
+        x = _d(x0).copy()
+        uu = _d(u_held) if u_held is not None else None
+        lib().orc_implicit_alpha(self.h, _p(x), t0, h, n_steps, n_iter, rho, amp, duration, idx, _p(uu) if uu is not None else None)
         return x
 
     def rk4_impulse_batch(self, X0, dt, n_steps, amps, duration=0.01, idx=-2, t0=0.0, n_threads=0):
