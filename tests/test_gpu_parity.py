@@ -1988,6 +1988,48 @@ def test_randomised_mixed_ensembles_against_oracle(seed):
         assert_blocks(ens.beam_state(b), w, obs[b].red2full(), 1e-6, what=("implicit", seed, b, int(sizes[b])))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_controlled_implicit_kernel_on_heterogeneous_ensembles(seed):
+    """crb_solve_controlled on ensembles whose beams differ in length, boundary conditions, material and ForceParams (per-beam
+    table ladders, per-beam error-norm sizes, each beam forced at its own tip): every beam's recorded states are its OWN
+    oracle's implicit-midpoint states for the step counts the controller accepted for THAT beam, interval by interval."""
+    from continuum_robot.batched import BeamEnsemble
+    from continuum_robot.models.force_params import ForceParams
+
+    rng = np.random.default_rng(7000 + seed)
+    B = int(rng.integers(2, 7))
+    sizes = rng.integers(40, 130, B) if seed % 3 == 2 else rng.integers(2, 30, B)
+    beams, fps = [], []
+    for b in range(B):
+        n = int(sizes[b])
+        bcs = ["FIXED" if i == 0 else ("PINNED" if rng.random() > 0.97 else "NONE") for i in range(n)]
+        beams.append(_scaled(nitinol_columns(n, "linear", bcs), rng))
+        fps.append(ForceParams(fluid_density=float(rng.uniform(500, 1500)), enable_fluid_effects=bool(rng.random() < 0.5),
+                               enable_gravity_effects=bool(rng.random() < 0.5),
+                               gravity_vector=[float(rng.uniform(-3, 3)), float(rng.uniform(-12, -6)), 0.0]))
+    ens = BeamEnsemble.from_dataframes(beams, force_params=fps)
+    obs = [oracle_beam(beams[b], fluid_density=fps[b].fluid_density, enable_fluid=fps[b].enable_fluid_effects,
+                       enable_gravity=fps[b].enable_gravity_effects, gravity=fps[b].get_gravity_vector()) for b in range(B)]
+    x0 = [rng.normal(0.0, 1e-5, 2 * ob.n) for ob in obs]
+    ens.set_state(ens.pad_states(x0))
+    amps = rng.uniform(0.01, 0.1, B)
+    dt_eval, n_int = 1e-3, 3
+    snaps, stats, used = ens.solve_controlled(n_int, dt_eval, rtol=1e-2, atol=1e-6, impulse_amp=amps, impulse_duration=1.5e-3,
+                                              first_rate=4.0 / dt_eval, t0=0.0)
+    assert np.all(stats[:, 2] == 0) and used.min() >= 2
+    y = ens.unpack_snapshots(snaps).cpu().numpy()            # [n_int, B, 2 n_max] padded
+    for b in range(B):
+        start = x0[b]
+        for k in range(n_int):
+            if k == 1:      # (the interval the impulse ends in is cut in two pieces with their own rungs: continue from the record)
+                start = ens.beam_state(b, y[k])
+                continue
+            m = int(used[b, k])
+            want = obs[b].implicit(start, dt_eval / m, m, n_iter=2, amp=amps[b], duration=1.5e-3, t0=k * dt_eval)
+            assert_blocks(ens.beam_state(b, y[k]), want, obs[b].red2full(), 5e-9, what=(seed, b, k, m, int(sizes[b])))
+            start = ens.beam_state(b, y[k])
+
+
 def test_example_scripts_run_and_agree_with_the_oracle():
     """examples/beam_comparison_ensemble.py (the reference's beam_comparison_* task lists as one ensemble) and
     examples/lqr_ensemble.py (its lqr_control.py loop over many impulses): both run, the comparison's linear dry rod
