@@ -49,6 +49,18 @@ def test_launch_without_device_fails_loudly():
     # the round-2 entry points refuse a host-only plan the same way (there is no CPU path behind any of them)
     with pytest.raises(nat.NativeError, match="no CPU path"):
         nat.check(nat.load().crb_step_implicit(plan.h, C.c_void_p(8), 0.0, 1e-3, 1, 2, None, None, None, None))
+    # ... and the round-3 ones: the controlled solver, the damped implicit stepper, per-group gains
+    lib = nat.load()
+    ctl = nat.ControlDesc(1e-3, 1e-6, 0.0, 0, 0, 0, 0)
+    with pytest.raises(nat.NativeError, match="no CPU path"):
+        nat.check(lib.crb_solve_controlled(plan.h, C.c_void_p(8), 0.0, 1e-3, 1, C.byref(ctl), None, None, None, None, C.c_void_p(8),
+                                           None, None))
+    with pytest.raises(nat.NativeError, match="no CPU path"):
+        nat.check(lib.crb_step_implicit_damped(plan.h, C.c_void_p(8), 0.0, 1e-3, 1, 2, 0.5, None, None, None, None))
+    groups = (C.c_int32 * 1)(0)
+    gains = (C.c_void_p * 1)(8)
+    with pytest.raises(nat.NativeError, match="no CPU path"):
+        nat.check(lib.crb_feedback_force_grouped(plan.h, C.c_void_p(8), 1, groups, gains, None, C.c_void_p(8), None))
     with pytest.raises(nat.NativeError, match="no CPU path"):
         plan.rhs_host(np.zeros(2 * plan.n_free))
     with pytest.raises(nat.NativeError, match="no CPU path"):
