@@ -66,7 +66,7 @@ class RecordDesc(C.Structure):
 
 class ControlDesc(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("first_rate", C.c_double), ("positions_only", C.c_int32),
-                ("n_iter", C.c_int32), ("max_rungs", C.c_int32), ("reserved", C.c_int32)]
+                ("n_iter", C.c_int32), ("max_rungs", C.c_int32), ("per_wave", C.c_int32)]
 
 
 class NativeError(RuntimeError):

@@ -507,8 +507,10 @@ class BeamEnsemble:
                  own step sequence, the whole span in ONE launch (``solve_controlled`` / crb_solve_controlled; the closed loop
                  only for gains that fit the LDS, beams of up to ~30 elements);  "host": the same controller as a host loop
                  over fixed-step launches, the worst beam deciding for the ensemble (``_solve_controlled``; any gain, through
-                 ``step_feedback``);  "auto": the device whenever it can and the ensemble fits two rounds of resident
-                 workgroups (2048 waves).
+                 ``step_feedback``);  "device-packed" (implicit scheme, beams of 2 .. 32 thread-carried nodes): G = 64 / slots
+                 beams share a wave and ONE step sequence, the worst of them deciding -- thousands of short beams fill the
+                 chip with a fifth of the waves;  "auto": the device whenever it can, packed once one workgroup per beam
+                 would need more than two rounds of resident waves (2048).
         Returns an object with ``t`` [n_t] and ``y`` [B, 2n, n_t] (``y[b]`` is the reference's ``sol.y`` of beam b,
         first column = the state at ``t_span[0]``), ``success``, ``method``; the resident state ends at the last
         ``t_eval`` point reached by whole intervals (RK45: at ``t_span[1]``)."""
@@ -554,8 +556,8 @@ class BeamEnsemble:
 
         t_switch = None if impulse_amp is None else float(impulse_duration)
         ctrl_stats = None
-        if controller not in ("auto", "device", "host"):
-            raise ValueError('controller must be "auto", "device" or "host"')
+        if controller not in ("auto", "device", "device-packed", "host"):
+            raise ValueError('controller must be "auto", "device", "device-packed" or "host"')
         if n_t == 1:
             ys = first
         elif gain is not None and not isinstance(substeps, str):
@@ -567,7 +569,8 @@ class BeamEnsemble:
             ys = torch.cat(out, dim=0)
         elif (stiff or gain is not None) and isinstance(substeps, str) and self._device_controller(controller, gain):
             snaps, stats, per_beam = self.solve_controlled(n_t - 1, dt_eval, rtol=rtol, atol=atol, control=control, gain=gain,
-                                                           reference=reference, t0=float(t_span[0]), **kw)
+                                                           reference=reference, t0=float(t_span[0]),
+                                                           per_wave=self._packs_per_wave(controller, gain), **kw)
             ys = torch.cat([first, self.unpack_snapshots(snaps)], dim=0)
             used = [int(v) for v in per_beam.max(axis=0)]
             ctrl_stats = (stats, per_beam)
@@ -605,7 +608,7 @@ class BeamEnsemble:
         if isinstance(substeps, str) and stiff and n_t > 1:
             sol.substeps = used      # steps per t_eval interval that the controller accepted (device: the most any beam took)
             if ctrl_stats is not None:
-                sol.controller = "device"
+                sol.controller = "device-packed" if self._packs_per_wave(controller, gain) else "device"
                 sol.substeps_per_beam = ctrl_stats[1]        # [B, n_t - 1]
                 sol.doublings = ctrl_stats[0][:, 1].copy()   # repeated pieces per beam
             else:
@@ -616,6 +619,8 @@ class BeamEnsemble:
         """Whether ``solve_ivp(substeps="auto")`` runs its controller inside the kernel (crb_solve_controlled's conditions)."""
         if controller == "host":
             return False
+        if controller == "device-packed":
+            controller = "device"
         ok = self.dtype == torch.float64 and int(self.plan.layout.threads) <= 256
         if ok and gain is not None:
             n2p = (2 * self.n + 7) // 8 * 8
@@ -624,17 +629,24 @@ class BeamEnsemble:
         if controller == "device" and not ok:
             raise ValueError("controller=\"device\": fp64 plans with beams of up to 256 thread-carried nodes; the closed loop "
                              "needs one gain that fits the LDS (beams of up to ~30 elements)")
-        if controller == "auto" and ok:
-            # one beam per workgroup at one wave per SIMD: 1024 waves are resident, larger ensembles run in rounds, and a
-            # homogeneous ensemble of short beams is then faster through the host loop's packed fixed-step launches
-            # (4096 x 10 elements, 1 s: 0.75 s against 0.28 s; 2 beams: 0.19 s against 0.25 s)
-            ok = self.n_beams * (int(self.plan.layout.threads) // 64) <= 2048
         return ok
+
+    def _packs_per_wave(self, controller, gain) -> bool:
+        """Whether the device controller packs short beams G to a wave (``per_wave``): asked for, or -- "auto" -- when one
+        workgroup per beam would need more than two rounds of resident waves (one wave per SIMD: 1024 waves are resident;
+        4096 x 10 elements for 1 s: 0.75 s with one beam per wave, the host loop 0.28 s)."""
+        lay = self.plan.layout
+        can = gain is None and int(lay.beams_per_group) > 1 and int(lay.pcr_levels_full) <= 5 and int(lay.pcr_levels_full) >= 1
+        if controller == "device-packed":
+            if not can:
+                raise ValueError("controller=\"device-packed\": implicit scheme, beams of 2 .. 32 thread-carried nodes")
+            return True
+        return controller == "auto" and can and self.n_beams * (int(lay.threads) // 64) > 2048
 
     def solve_controlled(self, n_intervals: int, dt_eval: float, rtol: float = 1e-3, atol: float = 1e-6, control: str = "all",
                          gain=None, reference=None, impulse_amp=None, impulse_duration: float = 0.01, impulse_index: int = -2,
                          held_force=None, t0: Optional[float] = None, n_iter: int = 2, first_rate: float = 0.0,
-                         max_rungs: int = 0, record: bool = True):
+                         max_rungs: int = 0, record: bool = True, per_wave: bool = False):
         """``n_intervals`` intervals of length ``dt_eval`` from the resident state with the step size chosen per beam by
         ``rtol`` / ``atol`` INSIDE the kernel, one launch (crb_solve_controlled, csrc/crb_ctrl.h): the implicit midpoint rule,
         or -- with ``gain`` -- RK4 with the feedback in every stage.  Returns (snapshots [n_intervals, B, 2, n_node, 4] or
@@ -655,7 +667,8 @@ class BeamEnsemble:
             keep.append(held)
         K = None if gain is None else self._dev(gain, (self.n, 2 * self.n))
         ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
-        ctl = nat.ControlDesc(float(rtol), float(atol), float(first_rate), int(control == "positions"), int(n_iter), int(max_rungs), 0)
+        ctl = nat.ControlDesc(float(rtol), float(atol), float(first_rate), int(control == "positions"), int(n_iter), int(max_rungs),
+                              int(bool(per_wave)))
         n_intervals = int(n_intervals)
         snaps = torch.zeros((n_intervals,) + tuple(self.state.shape), dtype=self.dtype, device=self.device) if record else None
         stats = torch.zeros((self.n_beams, 4), dtype=torch.int32, device=self.device)

@@ -61,19 +61,26 @@ template <typename T>
 __host__ __device__ constexpr size_t ctrl_lds_bytes(int NT, bool fb, int n, int lean_lognw = -1) {
     return (lean_lognw >= 0 ? implicit_lean_lds_bytes<T>(NT, lean_lognw)
                             : lds_bytes<T>(NT) + (fb ? (size_t(fb_padded(2 * n)) + size_t(fb_padded(2 * n)) * n) * sizeof(T) : 0)) +
-           8 * sizeof(double);
+           64 * sizeof(double);
 }
 
-template <typename T, int LV, bool FB, int LNW = -1, bool GRAV = false>
+// PACK (lean form, one wave): beams of fewer than 33 slots, G = 64 / S of them per wave (lane = g S + j) as in the packed
+// fixed-step kernels; the beams of a wave share ONE step sequence -- the worst of them decides -- so an ensemble of thousands
+// of short beams fills the chip with a fifth of the waves (control per group of G neighbours instead of per beam).
+template <typename T, int LV, bool FB, int LNW = -1, bool GRAV = false, bool PACK = false>
 __global__ void __launch_bounds__(LNW >= 0 ? (64 << LNW) : 256, 1)
 crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
     static_assert(sizeof(T) == 8, "the controlled steppers are fp64");
     static_assert(!(FB && LNW >= 0), "the closed loop runs the general RHS");
     static_assert(LNW < 0 || LV >= 1, "the lean form needs at least one reduction level");
+    static_assert(!PACK || LNW == 0, "packed beams live inside one wave");
     constexpr bool SLIM = LNW >= 0;
     constexpr int LOGNW = SLIM ? LNW : 0, NTL = 64 << LOGNW, NULLT = NTL;
     const int NT = blockDim.x;
-    const int beam = blockIdx.x;
+    const int pg = PACK ? int(threadIdx.x & 63) / p.S : 0;                 // beam of this lane inside the wave
+    const int beam_raw = PACK ? int(blockIdx.x) * p.G + pg : int(blockIdx.x);
+    const bool beam_ok = !PACK || (pg < p.G && beam_raw < p.B);
+    const int beam = beam_ok ? beam_raw : 0;
     const Lds<T> lds = carve_lds<T>(NT);
     // ---- topology: general (Topo) or lean (slot j of the beam in lane j >> LOGNW of wave j & (NW - 1))
     Topo tp;
@@ -82,11 +89,12 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
     tp.S = p.S;
     tp.lognw = p.lognw;
     tp.nwm1 = (1 << p.lognw) - 1;
-    if (SLIM) { tp.j = (tp.lane << LOGNW) | (tp.t >> 6); tp.base = 0; }
+    if (PACK) { tp.j = tp.lane - pg * p.S; tp.base = 0; }
+    else if (SLIM) { tp.j = (tp.lane << LOGNW) | (tp.t >> 6); tp.base = 0; }
     else if (p.lognw == 0) { tp.j = tp.t; tp.base = 0; }
     else { tp.j = (tp.lane << p.lognw) + (tp.t >> 6); tp.base = 0; }
     tp.beam = beam;
-    tp.valid = tp.j < p.S;
+    tp.valid = tp.j < p.S && beam_ok;
     const int jl = tp.j;                        // (lean form: the slot index also of a thread without a slot)
     if (!tp.valid) { tp.j = 0; tp.S = 1; tp.base = tp.t; tp.nwm1 = 0; }   // padding thread: an isolated dummy node
     const bool valid = tp.valid;
@@ -170,7 +178,7 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
     T* const fbx = lds.r1 + 3 * NT;            // [2n padded]     r - x of the stage
     T* const fbK = fbx + fb_n2p;               // [2n padded][n]  gain, transposed
     double* const red = SLIM ? reinterpret_cast<double*>(smem0 + size_t(NTL + 1) * size_t(12 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)))
-                             : reinterpret_cast<double*>(FB ? fbK + size_t(fb_n2p) * fb_n : fbx);   // [NT / 64]
+                             : reinterpret_cast<double*>(FB ? fbK + size_t(fb_n2p) * fb_n : fbx);   // [NT / 64]; PACK: [64]
     int ridx[3] = {-1, -1, -1};
     T rq[3] = {T(0), T(0), T(0)}, rv[3] = {T(0), T(0), T(0)};
     if (FB) {
@@ -290,7 +298,7 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
                     for (int c = 0; c < 3; ++c) { qp[c] = y[c] + hh * y[3 + c]; v0[c] = y[3 + c]; }
 #pragma unroll 1
                     for (int it = 0; it < q.n_iter; ++it)
-                        lean_implicit_iterate<T, LV, LOGNW, GRAV, EM_MIXED, false>(sc.elem, lin, shipped_nl, corrected, dragc, sc.half_mass,
+                        lean_implicit_iterate<T, LV, LOGNW, GRAV, EM_MIXED, PACK>(sc.elem, lin, shipped_nl, corrected, dragc, sc.half_mass,
                                                                                  hm_left, gx, gy, cf, ldsQ, ldsA, ldsB, tp.t, tp.lane, jl,
                                                                                  p.S, valid, has_left, has_right, t_l1, t_r1, t_r2, qp, v0,
                                                                                  uadd, hh, alpha, am);
@@ -334,16 +342,30 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
                 if (c < 3 || !q.positions_only) e2 += e * e;
             }
             if (!valid) e2 = 0.0;
+            if (PACK) {
+                // per beam: the sum over its S lanes (through LDS); per wave: the worst beam's estimate, a non-finite one as +inf
+                red[tp.lane] = e2;
+                __syncthreads();
+                double sum = 0.0;
+                for (int jj = 0; jj < p.S; ++jj) sum += red[(beam_ok ? pg : 0) * p.S + jj];
+                __syncthreads();
+                double eb = beam_ok ? sqrt(sum / n_norm) : 0.0;
+                eb = (eb == eb) ? eb : __builtin_huge_val();
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o, 64);
-            if (NT > 64) {
-                __syncthreads();
-                if (tp.lane == 0) red[tp.t >> 6] = e2;
-                __syncthreads();
-                e2 = 0.0;
-                for (int w = 0; w < NT / 64; ++w) e2 += red[w];
+                for (int o = 32; o > 0; o >>= 1) eb = fmax(eb, __shfl_xor(eb, o, 64));
+                err = eb;
+            } else {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o, 64);
+                if (NT > 64) {
+                    __syncthreads();
+                    if (tp.lane == 0) red[tp.t >> 6] = e2;
+                    __syncthreads();
+                    e2 = 0.0;
+                    for (int w = 0; w < NT / 64; ++w) e2 += red[w];
+                }
+                err = sqrt(e2 / n_norm);
             }
-            err = sqrt(e2 / n_norm);
             if (err <= 1.0) break;
             ++r;
             ++doublings;
@@ -358,7 +380,7 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
         in_interval += 2 << r;
         rate = double(1 << r) / P.len;
         if (err < SHRINK && r > 0) rate *= 0.5;
-        if (q.used && tp.t == 0 && (pc + 1 == q.n_pieces || q.pieces[pc + 1].interval != P.interval)) {
+        if (q.used && valid && tp.j == 0 && (pc + 1 == q.n_pieces || q.pieces[pc + 1].interval != P.interval)) {
             q.used[size_t(beam) * q.n_intervals + P.interval] = in_interval;
         }
         if (pc + 1 == q.n_pieces || q.pieces[pc + 1].interval != P.interval) in_interval = 0;
@@ -380,7 +402,7 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
         p.x[xoff + plane + 3] = T(0);
         mark_nonfinite<T>(p, beam, ys, ys + 3);
     }
-    if (tp.t == 0) {
+    if (valid && tp.j == 0) {
         int32_t* s = q.stats + size_t(beam) * CTRL_STATS;
         s[0] = int32_t(total > 0x7fffffffll ? 0x7fffffffll : total);
         s[1] = doublings;

@@ -3,24 +3,33 @@
 
 namespace crb {
 namespace {
-template <int LV, bool FB, int LNW = -1, bool GRAV = false>
+template <int LV, bool FB, int LNW = -1, bool GRAV = false, bool PACK = false>
 hipError_t one_controlled(const KParams<double>& k, const CtrlParams<double>& q, int threads, size_t lds, hipStream_t st) {
-    auto kern = crb_controlled_kernel<double, LV, FB, LNW, GRAV>;
+    auto kern = crb_controlled_kernel<double, LV, FB, LNW, GRAV, PACK>;
     if (lds > size_t(48) * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(k.B), dim3(threads), lds, st, k, q);
+    hipLaunchKernelGGL(kern, dim3(PACK ? (k.B + k.G - 1) / k.G : k.B), dim3(threads), lds, st, k, q);
     return hipGetLastError();
 }
 }  // namespace
 
 hipError_t launch_controlled(const KParams<double>& k, const CtrlParams<double>& q, int levels, bool feedback, int lean_lognw, bool grav,
-                             int threads, size_t lds, hipStream_t st) {
+                             bool pack, int threads, size_t lds, hipStream_t st) {
     if (threads < 64 || threads > 256 || (threads & 63)) return hipErrorInvalidValue;
 #ifdef CRB_FAST_BUILD
     return hipErrorInvalidValue;
 #else
+    if (pack) {   // several short beams per wave (k.G of them, fewer than 33 slots each), one step sequence per wave
+        if (feedback || lean_lognw != 0 || threads != 64 || k.G < 2) return hipErrorInvalidValue;
+#define CRB_CTRL_PACK(LVV) \
+        if (levels == LVV) \
+            return grav ? one_controlled<LVV, false, 0, true, true>(k, q, threads, lds, st) : one_controlled<LVV, false, 0, false, true>(k, q, threads, lds, st);
+        CRB_CTRL_PACK(1) CRB_CTRL_PACK(2) CRB_CTRL_PACK(3) CRB_CTRL_PACK(4) CRB_CTRL_PACK(5)
+#undef CRB_CTRL_PACK
+        return hipErrorInvalidValue;
+    }
     if (lean_lognw >= 0) {   // the lean iteration: all ceil(log2 S) levels of a beam of 2 .. 64 / 65 .. 128 / 129 .. 256 slots
         if (feedback || threads != (64 << lean_lognw)) return hipErrorInvalidValue;
 #define CRB_CTRL_LEAN(LVV, NWW) \

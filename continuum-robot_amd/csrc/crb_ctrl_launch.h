@@ -12,6 +12,8 @@ namespace crb {
 // covers the plan (more than 8 / 6 levels).
 // lean_lognw >= 0 (implicit scheme): the lean iteration with 2^lean_lognw waves per beam (threads = 64 << lean_lognw, levels =
 // ceil(log2 S) >= 1), gravity absent or canonical (`grav`); -1: the general RHS.
+// pack (lean form with lean_lognw == 0, k.G >= 2 beams of fewer than 33 slots per wave): a grid of ceil(k.B / k.G) one-wave
+// workgroups, every wave with ONE step sequence for its beams.
 hipError_t launch_controlled(const KParams<double>& k, const CtrlParams<double>& q, int levels, bool feedback, int lean_lognw, bool grav,
-                             int threads, size_t lds_bytes, hipStream_t st);
+                             bool pack, int threads, size_t lds_bytes, hipStream_t st);
 }  // namespace crb

@@ -1687,7 +1687,12 @@ extern "C" int crb_solve_controlled(const crb_plan* p, void* x, double t0, doubl
     const bool lean = !fb && p->levels_full >= 1 && p->lognw <= 2 && threads == (64 << p->lognw) && (!grav || p->canonical_gravity) &&
                       std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr;
     const int lean_lognw = lean ? p->lognw : -1;
-    HIP_TRY(crb::launch_controlled(k, q, fb ? p->levels : p->levels_full, fb, lean_lognw, grav, threads,
+    // per_wave: short beams packed G to a wave, one step sequence per wave (the worst of its beams decides)
+    const bool pack = ctl->per_wave != 0 && lean && p->G > 1 && p->lognw == 0 && p->levels_full <= 5;
+    if (ctl->per_wave != 0 && !pack)
+        return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: per_wave packs beams of 2 .. 32 thread-carried nodes of the implicit scheme (gravity absent or canonical)");
+    if (pack) k.G = p->G;
+    HIP_TRY(crb::launch_controlled(k, q, fb ? p->levels : p->levels_full, fb, lean_lognw, grav, pack, threads,
                                    ctrl_lds_bytes<double>(threads, fb, p->n_free, lean_lognw), st));
     return CRB_OK;
 }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRB_VERSION 104
+#define CRB_VERSION 105
 
 enum { CRB_OK = 0, CRB_EINVAL = -1, CRB_EHIP = -2, CRB_ENODEV = -3, CRB_EUNSUPPORTED = -4 };
 enum { CRB_F64 = 0, CRB_F32 = 1 };
@@ -270,7 +270,9 @@ typedef struct crb_control_desc {
     int32_t positions_only;  /* measure the position half of the state only */
     int32_t n_iter;          /* implicit scheme: modified-Newton iterations per step; <= 0: 2 */
     int32_t max_rungs;       /* <= 0: 15 */
-    int32_t reserved;
+    int32_t per_wave;        /* 0: every beam its own step sequence (one workgroup per beam).  1 (implicit scheme, beams of 2 .. 32
+                              * thread-carried nodes): G = 64 / n_slots beams share a wave AND its step sequence -- the worst of them
+                              * decides -- so thousands of short beams fill the chip with a fifth of the waves */
 } crb_control_desc;
 int crb_solve_controlled(const crb_plan* plan, void* x, double t0, double dt_eval, int n_intervals,
                          const crb_control_desc* control, const crb_input_desc* input, const void* gain, const void* ref,

@@ -22,7 +22,7 @@ def blocks(n):
 def run(name, T, times, tight, dflt, B=2, **tol):
     cols, kw = beam_columns(g8, name), force_kwargs(g8, name)
     t_eval = np.arange(0.0, T + 0.0005, 0.001)
-    for ctrl in ("device", "host"):
+    for ctrl in ("device", "device-packed", "host"):
         ens = ensemble(cols, B, kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -36,7 +36,7 @@ def ensemble(cols, n_beams, kw=None, dtype=None, node_bc=None, corrected_axial=F
 def test_native_library_is_the_loaded_path():
     from continuum_robot import _native as nat
 
-    assert nat.load().crb_version() == 104
+    assert nat.load().crb_version() == 105
     assert torch.cuda.is_available()
 
 
@@ -1852,6 +1852,52 @@ def test_controlled_closed_loop_kernel_takes_the_oracles_steps(golden, name):
             x = ob.rk4_feedback(x, dt_eval / m, m, K, amp=amps[b], duration=0.0025, t0=k * dt_eval)
             assert_blocks(y[k, b], x, ens.free_index, 1e-9, what=(b, k, m))
             x = y[k, b].copy()
+
+
+@pytest.mark.parametrize("n_e,kw", [(3, dict(enable_gravity=True)), (10, dict(enable_gravity=True)),
+                                     (10, dict(fluid_density=1000.0, enable_fluid=True)), (20, dict()), (31, dict(enable_gravity=True))])
+def test_packed_controlled_kernel_shares_a_step_sequence_per_wave(n_e, kw):
+    """crb_solve_controlled with ``per_wave`` (``controller="device-packed"``): G = 64 / slots short beams per wave, ONE step
+    sequence per wave -- the worst of its beams decides.  Every beam's recorded states are still its own oracle's
+    implicit-midpoint states for the accepted step counts; the beams of a wave report the same counts; a beam never takes
+    FEWER steps than it does when it decides alone; and the last, partly filled wave is handled."""
+    cols = nitinol_columns(n_e, "linear")
+    ens = ensemble(cols, 1, kw)
+    G = int(ens.plan.layout.beams_per_group)
+    assert G == 64 // int(ens.plan.layout.n_slots) and G >= 2
+    B = 2 * G + 1                                        # two full waves and one beam in a third
+    ens = ensemble(cols, B, kw)
+    ob = oracle_beam(cols, **kw)
+    rng = np.random.default_rng(n_e)
+    x0 = 1e-5 * rng.standard_normal((B, 2 * ens.n))
+    amps = np.where(np.arange(B) % G == 1, 0.2, 1e-3)    # one hard-hit beam per wave
+    amps[-1] = 0.0
+    dt_eval, n_int = 1e-3, 4
+    ens.set_state(x0)
+    snaps, stats, used = ens.solve_controlled(n_int, dt_eval, rtol=1e-3, atol=1e-6, impulse_amp=amps, impulse_duration=2e-3, t0=0.0,
+                                              per_wave=True)
+    y = ens.unpack_snapshots(snaps).cpu().numpy()
+    assert np.all(stats[:, 2] == 0)
+    for w in range(3):
+        rows = used[w * G:min((w + 1) * G, B)]
+        assert np.all(rows == rows[0]), (w, rows)
+    for b in (0, 1, G - 1, G, G + 1, 2 * G):
+        for k in range(n_int):
+            start = x0[b] if k == 0 else y[k - 1, b]
+            m = int(used[b, k])
+            want = ob.implicit(start, dt_eval / m, m, n_iter=2, amp=amps[b], duration=2e-3, t0=k * dt_eval)
+            assert_blocks(y[k, b], want, ens.free_index, 2e-9, what=(b, k, m))
+    alone = ensemble(cols, B, kw)
+    alone.set_state(x0)
+    _, _, used_alone = alone.solve_controlled(n_int, dt_eval, rtol=1e-3, atol=1e-6, impulse_amp=amps, impulse_duration=2e-3, t0=0.0)
+    assert np.all(used.sum(axis=1) >= used_alone.sum(axis=1)) and used.sum() > used_alone.sum()
+    # solve_ivp takes the packed form when asked, and refuses it where it does not exist
+    e2 = ensemble(cols, B, kw)
+    sol = e2.solve_ivp((0.0, 0.0035), np.arange(0.0, 0.0035, 0.001), method="LSODA", impulse_amp=amps, controller="device-packed")
+    assert sol.controller == "device-packed" and sol.substeps_per_beam.shape == (B, 3)
+    big = ensemble(nitinol_columns(70, "linear"), 2, kw)
+    with pytest.raises(ValueError, match="device-packed"):
+        big.solve_ivp((0.0, 0.0035), np.arange(0.0, 0.0035, 0.001), method="LSODA", controller="device-packed")
 
 
 def test_controlled_steppers_give_every_beam_its_own_step_sequence(golden):
