@@ -2076,6 +2076,64 @@ def test_controlled_implicit_kernel_on_heterogeneous_ensembles(seed):
             start = ens.beam_state(b, y[k])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CRB_FUZZ_CTRL_N", "16"))))   # CRB_FUZZ_CTRL_N=300 for a long hunt
+def test_randomised_controlled_runs_replay_on_the_oracle(seed):
+    """Differential test of crb_solve_controlled over random shapes (1 .. 200 elements: every instance family of the kernel),
+    element kinds, boundary conditions, forces, tolerances, first rates, impulse timing (on the grid, inside an interval, or
+    absent), a held force, the position-only norm and the packed form: whatever step counts the controller accepts, each
+    recorded interval is the oracle's implicit-midpoint result for that count from the recorded start of the interval."""
+    rng = np.random.default_rng(9000 + seed)
+    n_e = int(rng.choice([1, 2, 3, 5, 8, 10, 13, 16, 21, 31, 33, 47, 64, 65, 100, 128, 129, 200]))
+    kind = "nonlinear" if (n_e <= 5 and rng.random() < 0.5) else "linear"
+    bcs = ["FIXED"] + [("PINNED" if rng.random() > 0.97 else "NONE") for _ in range(n_e - 1)]
+    cols = _scaled(nitinol_columns(n_e, kind, bcs), rng)
+    kw = dict()
+    if rng.random() < 0.5:
+        kw.update(enable_gravity=True)
+    if rng.random() < 0.5:
+        kw.update(fluid_density=float(rng.uniform(500, 1500)), enable_fluid=True)
+    B = int(rng.integers(1, 12))
+    ens = ensemble(cols, B, kw)
+    ob = oracle_beam(cols, **kw)
+    x0 = float(rng.choice([0.0, 1e-6, 1e-4])) * rng.standard_normal((B, 2 * ens.n))
+    amps = rng.uniform(0.0, 0.2, B)
+    dt_eval = float(rng.choice([5e-4, 1e-3, 2e-3]))
+    n_int = int(rng.integers(2, 5))
+    mode = int(rng.integers(0, 3))                       # impulse: ends on the grid / inside interval 1 / absent
+    t_sw = {0: dt_eval, 1: 1.37 * dt_eval, 2: None}[mode]
+    held = 0.02 * rng.standard_normal((B, ens.n)) if rng.random() < 0.3 else None
+    packable = int(ens.plan.layout.beams_per_group) > 1 and 1 <= int(ens.plan.layout.pcr_levels_full) <= 5
+    per_wave = bool(packable and rng.random() < 0.5)
+    control = "positions" if rng.random() < 0.3 else "all"
+    args = dict(rtol=float(rng.choice([1e-2, 1e-3, 1e-4])), atol=float(rng.choice([1e-5, 1e-7])),
+                impulse_amp=None if mode == 2 else amps, impulse_duration=t_sw if t_sw else 0.01, held_force=held,
+                first_rate=float(rng.choice([0.0, 2.0, 64.0])) / dt_eval, t0=0.0, control=control, max_rungs=12)
+    ens.set_state(x0)
+    try:
+        try:
+            snaps, stats, used = ens.solve_controlled(n_int, dt_eval, per_wave=per_wave, **args)
+        except Exception as e:                            # (a pinned interior node makes gravity non-canonical: no packed form)
+            if not (per_wave and "per_wave" in str(e)):
+                raise
+            per_wave = False
+            ens.set_state(x0)
+            snaps, stats, used = ens.solve_controlled(n_int, dt_eval, **args)
+    except RuntimeError as e:                             # (a tolerance the ladder of 12 rungs cannot meet is a legitimate outcome)
+        assert "tolerances ask for more" in str(e)
+        return
+    y = ens.unpack_snapshots(snaps).cpu().numpy()
+    assert np.all(stats[:, 2] == 0) and np.all(np.isfinite(y))
+    for b in range(B):
+        for k in range(n_int):
+            if mode == 1 and k == 1:
+                continue                                  # (the cut interval: two pieces with their own step counts)
+            start = x0[b] if k == 0 else y[k - 1, b]
+            m = int(used[b, k])
+            want = ob.implicit(start, dt_eval / m, m, n_iter=2, amp=0.0 if mode == 2 else amps[b], duration=t_sw if t_sw else 0.0,
+                               t0=k * dt_eval, u_held=None if held is None else held[b])
+            assert_blocks(y[k, b], want, ens.free_index, 5e-9, what=(seed, n_e, kind, b, k, m, per_wave, control))
+
+
 def test_example_scripts_run_and_agree_with_the_oracle():
     """examples/beam_comparison_ensemble.py (the reference's beam_comparison_* task lists as one ensemble) and
     examples/lqr_ensemble.py (its lqr_control.py loop over many impulses): both run, the comparison's linear dry rod
