@@ -17,8 +17,8 @@
 //           L only ever takes h = L / 2^r, so the host pre-factorises the LADDER r = 0 .. n_rungs-1 for each distinct
 //           piece length (at most three: whole intervals and the two parts of the interval the impulse ends in) with
 //           crb_assemble_kernel before the launch; the kernel re-reads its rows (L2-resident) when r changes.
-// One workgroup per beam (beams shorter than a wave are NOT packed: every beam has its own step sequence), one
-// thread per node, state and tables in registers.  fp64.
+// One workgroup per beam (every beam has its own step sequence; the PACK instances below put several short beams into one
+// wave, which then share a sequence), one thread per node, state and tables in registers, one wave per SIMD.  fp64.
 // LNW < 0: the general RHS (stage_accel: any gravity table, run-time topology).  LNW = 0..2 (implicit scheme): the lean
 // iteration of crb_stiff.h with 2^LNW waves per beam -- lane shifts instead of LDS round trips, gravity absent or of the
 // plain cantilever's form (GRAV): 2.2 instead of 3.8 us per step for the 10-element example.
