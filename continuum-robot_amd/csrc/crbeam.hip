@@ -1673,7 +1673,7 @@ extern "C" int crb_solve_controlled(const crb_plan* p, void* x, double t0, doubl
     k.imp_slot = imp_slot; k.imp_dof = imp_dof; k.duration = t_switch;
     k.imp_node_b = impulse ? in->node_b : nullptr;
     k.t0 = t0;
-    arm_status(p, k, 0);
+    arm_status(p, k, 1);   // (per-beam status, crb_plan_set_status: a controlled launch counts as one step of the ensemble)
     if (fb) {
         if (int rc = ensure_red_map(p)) return rc;
         k.red_map = p->d_red_map;
