@@ -624,7 +624,7 @@ class BeamEnsemble:
         ok = self.dtype == torch.float64 and int(self.plan.layout.threads) <= 256
         if ok and gain is not None:
             n2p = (2 * self.n + 7) // 8 * 8
-            lds = 14 * int(self.plan.layout.threads) * 8 + (n2p + n2p * self.n) * 8 + 64
+            lds = 14 * int(self.plan.layout.threads) * 8 + (n2p + n2p * self.n + 32) * 8 + 512
             ok = not isinstance(gain, (list, tuple)) and not self.mixed_topology and lds <= 160 * 1024
         if controller == "device" and not ok:
             raise ValueError("controller=\"device\": fp64 plans with beams of up to 256 thread-carried nodes; the closed loop "

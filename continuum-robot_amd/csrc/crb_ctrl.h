@@ -60,7 +60,7 @@ struct CtrlParams {
 template <typename T>
 __host__ __device__ constexpr size_t ctrl_lds_bytes(int NT, bool fb, int n, int lean_lognw = -1) {
     return (lean_lognw >= 0 ? implicit_lean_lds_bytes<T>(NT, lean_lognw)
-                            : lds_bytes<T>(NT) + (fb ? (size_t(fb_padded(2 * n)) + size_t(fb_padded(2 * n)) * n) * sizeof(T) : 0)) +
+                            : lds_bytes<T>(NT) + (fb ? (size_t(fb_padded(2 * n)) + size_t(fb_padded(2 * n)) * n + FBM_UPAD) * sizeof(T) : 0)) +
            64 * sizeof(double);
 }
 
@@ -177,8 +177,11 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
     const int fb_n = p.n_red, fb_n2 = 2 * p.n_red, fb_n2p = fb_padded(fb_n2);
     T* const fbx = lds.r1 + 3 * NT;            // [2n padded]     r - x of the stage
     T* const fbK = fbx + fb_n2p;               // [2n padded][n]  gain, transposed
+    T* const fbu = fbK + size_t(fb_n2p) * fb_n;   // [FBM_UPAD]      K e of the stage (matrix-core form, crb_generic.h)
+    const bool fb_mfma = FB && fb_on_matrix_cores(1, fb_n);
+    T fb_af[FBM_MT][FBM_KS];
     double* const red = SLIM ? reinterpret_cast<double*>(smem0 + size_t(NTL + 1) * size_t(12 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)))
-                             : reinterpret_cast<double*>(FB ? fbK + size_t(fb_n2p) * fb_n : fbx);   // [NT / 64]; PACK: [64]
+                             : reinterpret_cast<double*>(FB ? fbu + FBM_UPAD : fbx);   // [NT / 64]; PACK: [64]
     int ridx[3] = {-1, -1, -1};
     T rq[3] = {T(0), T(0), T(0)}, rv[3] = {T(0), T(0), T(0)};
     if (FB) {
@@ -199,6 +202,7 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
         for (int idx = tp.t; idx < (fb_n2p - fb_n2) * fb_n; idx += NT) fbK[size_t(fb_n2) * fb_n + idx] = T(0);
         for (int idx = tp.t; idx < fb_n2p - fb_n2; idx += NT) fbx[fb_n2 + idx] = T(0);
         __syncthreads();
+        if (fb_mfma) fbm_gain_fragments<T>(fb_af, fbK, fb_n, fb_n2p, tp.lane);
     }
 
     constexpr double ORDER_DIV = FB ? 15.0 : 3.0;          // 2^order - 1
@@ -258,7 +262,14 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
                                 if (ridx[c] >= 0) { fbx[ridx[c]] = rq[c] - xs[c]; fbx[fb_n + ridx[c]] = rv[c] - xs[3 + c]; }
                         }
                         __syncthreads();
-                        if (valid) {
+                        if (fb_mfma) {
+                            fbm_product<T>(fb_af, fbx, fbu, 1, fb_n, fb_n2p, tp.lane);
+                            __syncthreads();
+                            if (valid) {
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) ua[c] += ridx[c] >= 0 ? fbu[ridx[c]] : T(0);
+                            }
+                        } else if (valid) {
                             const int i0 = ridx[0] >= 0 ? ridx[0] : 0, i1 = ridx[1] >= 0 ? ridx[1] : 0, i2 = ridx[2] >= 0 ? ridx[2] : 0;
                             T u0 = T(0), u1 = T(0), u2 = T(0);
                             for (int k = 0; k < fb_n2p; k += FB_BATCH) {

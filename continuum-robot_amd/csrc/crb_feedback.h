@@ -20,17 +20,7 @@ namespace crb {
 // D: col j = l&15, row i = (l>>4) + 4*reg.
 // the MFMA of each dtype: A / B fragments are one value per lane (A[i = lane & 15][k = lane >> 4]) for both,
 // the C/D row of accumulator register `reg` differs (cdna_hip_programming.md, 'Fragment layout')
-template <typename T> struct MfmaOps;
-template <> struct MfmaOps<double> {
-    typedef double acc_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
-};
-template <> struct MfmaOps<float> {
-    typedef float acc_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
-};
+// (MfmaOps<T>: the matrix instruction of each dtype and its C/D row map -- crb_generic.h, shared with the fused small-beam loop)
 template <typename T>
 struct FeedbackParams {
     const T* xs;       // [B][2][n_node][4]

@@ -299,9 +299,69 @@ __device__ __forceinline__ Lds<T> carve_lds(int NT) {
 // (<= ~28 elements); larger ensembles take the stage-split path (one MFMA GEMM per stage, crb_feedback.h).
 constexpr int FB_BATCH = 8;
 __host__ __device__ constexpr int fb_padded(int n2) { return (n2 + FB_BATCH - 1) / FB_BATCH * FB_BATCH; }
+// Gains of 21 .. FBM_N rows (beams of 7 .. 10 elements: the reference's examples) take the product K e to the matrix cores:
+// U^T = K E^T with the GAIN as the A operand -- its fragments (2 row tiles x 16 k-steps = 32 values per lane) are loaded into
+// registers once per launch -- and the stage's error vectors of the wave's beams as the B operand (16 LDS reads per lane and
+// stage instead of 240 per thread); 32 matrix instructions per stage whatever the number of beams in the wave (<= 16).
+constexpr int FBM_N = 32, FBM_MT = 2, FBM_KS = 16, FBM_UPAD = 32;
+// (the fixed 32 instructions beat the batched LDS product from ~20 rows on: 64 x 10 elements 14.1 against 17.0 us per step,
+//  64 x 6 elements 13.7 against 12.8)
+__host__ __device__ constexpr bool fb_on_matrix_cores(int G, int n) { return n > 20 && n <= FBM_N && G <= 16; }
 template <typename T>
 __host__ __device__ constexpr size_t fb_lds_bytes(int NT, int G, int n) {
-    return lds_bytes<T>(NT) + (size_t(G) * fb_padded(2 * n) + size_t(fb_padded(2 * n)) * n) * sizeof(T);
+    return lds_bytes<T>(NT) + (size_t(G) * fb_padded(2 * n) + size_t(fb_padded(2 * n)) * n + (fb_on_matrix_cores(G, n) ? size_t(G) * FBM_UPAD : 0)) * sizeof(T);
+}
+// the MFMA of each dtype: A / B fragments are one value per lane (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15])
+// for both, the C/D row of accumulator register `reg` differs (cdna_hip_programming.md, 'Fragment layout')
+template <typename T> struct MfmaOps;
+template <> struct MfmaOps<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct MfmaOps<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
+template <typename T>
+__device__ __forceinline__ void fbm_gain_fragments(T (&af)[FBM_MT][FBM_KS], const T* fbK, int n, int n2p, int lane) {
+    const int fi = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < FBM_MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < FBM_KS; ++ks) {
+            const int i = 16 * mt + fi, k = 4 * ks + kq;
+            af[mt][ks] = (i < n && k < n2p) ? fbK[size_t(k) * n + i] : T(0);     // (fbK is the transposed gain, its padding rows are 0)
+        }
+}
+// fbu[g][i] = (K e_g)[i] for the G beams of the wave (e_g = fbx + g n2p); whole wave, the caller puts barriers around it
+template <typename T>
+__device__ __forceinline__ void fbm_product(const T (&af)[FBM_MT][FBM_KS], const T* fbx, T* fbu, int G, int n, int n2p, int lane) {
+    typedef typename MfmaOps<T>::acc_t acc4;
+    const int fj = lane & 15, kq = lane >> 4;
+    const T* ecol = fbx + size_t(fj < G ? fj : 0) * n2p + kq;
+    T ef[FBM_KS];
+#pragma unroll
+    for (int ks = 0; ks < FBM_KS; ++ks) ef[ks] = (fj < G && 4 * ks + kq < n2p) ? ecol[4 * ks] : T(0);
+    acc4 acc[FBM_MT];
+#pragma unroll
+    for (int mt = 0; mt < FBM_MT; ++mt) acc[mt] = acc4{T(0), T(0), T(0), T(0)};
+    // (all FBM_KS x FBM_MT products, also where the padding makes them products of zeros: skipping those under wave-uniform
+    //  branches breaks the two accumulator chains apart -- measured 17.8 instead of 14.1 us per step for a 10-element beam)
+#pragma unroll
+    for (int ks = 0; ks < FBM_KS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < FBM_MT; ++mt) acc[mt] = MfmaOps<T>::run(af[mt][ks], ef[ks], acc[mt]);
+    if (fj < G) {
+#pragma unroll
+        for (int mt = 0; mt < FBM_MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = 16 * mt + MfmaOps<T>::row(lane, reg);
+                if (i < n) fbu[size_t(fj) * FBM_UPAD + i] = acc[mt][reg];
+            }
+    }
 }
 template <typename T, int MODE, int LV, int MAXT, int MINW, bool LEAN, bool FB = false>
 __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p) {
@@ -403,6 +463,9 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
     const int fb_n = p.n_red, fb_n2 = 2 * p.n_red, fb_n2p = fb_padded(fb_n2);
     T* const fbx = lds.r1 + 3 * NT;                       // [G][2n padded]  r - x of the stage, per beam of the workgroup
     T* const fbK = fbx + size_t(p.G) * fb_n2p;            // [2n padded][n]  gain, transposed
+    T* const fbu = fbK + size_t(fb_n2p) * fb_n;           // [G][FBM_UPAD]   K e of the stage (matrix-core form)
+    const bool fb_mfma = FB && fb_on_matrix_cores(p.G, fb_n);
+    T fb_af[FBM_MT][FBM_KS];
     T rq[3] = {T(0), T(0), T(0)}, rv[3] = {T(0), T(0), T(0)};
     if (FB) {
         if (valid) {
@@ -423,6 +486,7 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
         for (int idx = tp.t; idx < p.G * (fb_n2p - fb_n2); idx += NT)
             fbx[size_t(idx / (fb_n2p - fb_n2)) * fb_n2p + fb_n2 + idx % (fb_n2p - fb_n2)] = T(0);
         __syncthreads();
+        if (fb_mfma) fbm_gain_fragments<T>(fb_af, fbK, fb_n, fb_n2p, tp.lane);
     }
 
     if (MODE == MODE_STAGE) {
@@ -533,7 +597,15 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
                         if (red[c] >= 0) { e[red[c]] = rq[c] - xs[c]; e[fb_n + red[c]] = rv[c] - xs[3 + c]; }
                 }
                 __syncthreads();
-                if (valid) {
+                if (fb_mfma) {
+                    fbm_product<T>(fb_af, fbx, fbu, p.G, fb_n, fb_n2p, tp.lane);
+                    __syncthreads();
+                    if (valid) {
+                        const T* ub = fbu + size_t(g) * FBM_UPAD;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) uadd[c] += red[c] >= 0 ? ub[red[c]] : T(0);
+                    }
+                } else if (valid) {
                     const int i0 = red[0] >= 0 ? red[0] : 0, i1 = red[1] >= 0 ? red[1] : 0, i2 = red[2] >= 0 ? red[2] : 0;
                     T u0 = T(0), u1 = T(0), u2 = T(0);
                     // K e in batches of FB_BATCH columns: all LDS loads of a batch are issued before its first multiply-add

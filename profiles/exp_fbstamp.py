@@ -1,9 +1,7 @@
-"""Experiment (round 3, not taken): step time of the fused small-beam closed loop (gain in LDS) for 6 / 10 / 20 elements x 64 beams,
-next to the open-loop lean stepper.  In-kernel stamps put a stage of the 10-element loop at ~4500 cycles for the product K e (240
-LDS reads + 180 multiply-adds per thread, batches of 8 columns) and ~4000 for the right-hand side.  Variants measured against
-that: the product on the matrix cores (E of the wave's G <= 9 beams as one 16-row tile: 6500 cycles -- most of the tile is
-padding and every k-step waits for its LDS fragments), batches whose loads run one batch ahead (26.8 instead of 17.0 us per
-step), batches of 16 (14.4 / 17.3 / 26.4 against 12.8 / 17.0 / 25.9 us per step).  usage: python profiles/exp_fbstamp.py"""
+"""Experiment (round 3): step time of the fused small-beam closed loop (gain in LDS) for 6 / 10 / 20 elements x 64 beams, next to the
+open-loop lean stepper; DESIGN.md section 7 ("Fused small-beam closed loop, round 3") lists what was measured with it and which
+variant was taken (the product K e on the matrix cores with the gain as the resident A operand, for gains of 21 .. 32 rows).
+usage: python profiles/exp_fbstamp.py"""
 import os, sys, ctypes as C, time
 ROOT = "/root/repo"
 sys.path[:0] = [ROOT, os.path.join(ROOT, "continuum-robot_amd"), os.path.join(ROOT, "examples")]
