@@ -261,33 +261,10 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
                             for (int c = 0; c < 3; ++c)
                                 if (ridx[c] >= 0) { fbx[ridx[c]] = rq[c] - xs[c]; fbx[fb_n + ridx[c]] = rv[c] - xs[3 + c]; }
                         }
-                        __syncthreads();
-                        if (fb_mfma) {
-                            fbm_product<T>(fb_af, fbx, fbu, 1, fb_n, fb_n2p, tp.lane);
-                            __syncthreads();
-                            if (valid) {
+                        T ufb[3];
+                        fb_feedback<T>(fb_mfma, fb_af, fbx, fbK, fbu, 1, 0, fb_n, fb_n2p, tp.lane, valid, ridx, ufb);
 #pragma unroll
-                                for (int c = 0; c < 3; ++c) ua[c] += ridx[c] >= 0 ? fbu[ridx[c]] : T(0);
-                            }
-                        } else if (valid) {
-                            const int i0 = ridx[0] >= 0 ? ridx[0] : 0, i1 = ridx[1] >= 0 ? ridx[1] : 0, i2 = ridx[2] >= 0 ? ridx[2] : 0;
-                            T u0 = T(0), u1 = T(0), u2 = T(0);
-                            for (int k = 0; k < fb_n2p; k += FB_BATCH) {
-                                T ek[FB_BATCH], r0[FB_BATCH], r1[FB_BATCH], r2[FB_BATCH];
-#pragma unroll
-                                for (int qq = 0; qq < FB_BATCH; ++qq) {
-                                    const T* row = fbK + size_t(k + qq) * fb_n;
-                                    ek[qq] = fbx[k + qq]; r0[qq] = row[i0]; r1[qq] = row[i1]; r2[qq] = row[i2];
-                                }
-                                __builtin_amdgcn_sched_group_barrier(0x100, 4 * FB_BATCH, 0);
-#pragma unroll
-                                for (int qq = 0; qq < FB_BATCH; ++qq) { u0 += r0[qq] * ek[qq]; u1 += r1[qq] * ek[qq]; u2 += r2[qq] * ek[qq]; }
-                                __builtin_amdgcn_sched_group_barrier(0x002, 3 * FB_BATCH, 0);
-                            }
-                            ua[0] += ridx[0] >= 0 ? u0 : T(0);
-                            ua[1] += ridx[1] >= 0 ? u1 : T(0);
-                            ua[2] += ridx[2] >= 0 ? u2 : T(0);
-                        }
+                        for (int c = 0; c < 3; ++c) ua[c] += ufb[c];
                         __syncthreads();   // (several waves per beam: every wave has read the error vector before the next stage overwrites it)
                         stage_accel<T, LV, false, false>(p, lds, sc, cf, tp, xs, xs + 3, ua, a);
                         const T w = (s == 0 || s == 3) ? T(1) : T(2);

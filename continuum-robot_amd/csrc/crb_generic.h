@@ -311,6 +311,10 @@ template <typename T>
 __host__ __device__ constexpr size_t fb_lds_bytes(int NT, int G, int n) {
     return lds_bytes<T>(NT) + (size_t(G) * fb_padded(2 * n) + size_t(fb_padded(2 * n)) * n + (fb_on_matrix_cores(G, n) ? size_t(G) * FBM_UPAD : 0)) * sizeof(T);
 }
+template <typename T>
+__host__ __device__ constexpr size_t fb_lean_lds_bytes(int G, int n) {   // the feedback form of the packed lean stepper: no exchange columns
+    return (size_t(G) * fb_padded(2 * n) + size_t(fb_padded(2 * n)) * n + size_t(G) * FBM_UPAD) * sizeof(T);
+}
 // the MFMA of each dtype: A / B fragments are one value per lane (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15])
 // for both, the C/D row of accumulator register `reg` differs (cdna_hip_programming.md, 'Fragment layout')
 template <typename T> struct MfmaOps;
@@ -363,6 +367,50 @@ __device__ __forceinline__ void fbm_product(const T (&af)[FBM_MT][FBM_KS], const
             }
     }
 }
+// The three entries of K e that belong to one node, rows i0 / i1 / i2 of the gain (fbK: its transpose in LDS), in batches of
+// FB_BATCH columns: all LDS loads of a batch are issued before its first multiply-add (one wave per SIMD here, nothing else
+// hides the LDS latency; left to itself the scheduler alternates load / wait / multiply-add: 200 cycles per column).  The
+// column count is padded to a multiple of the batch with zero columns.
+template <typename T>
+__device__ __forceinline__ void fb_product_lds(const T* e, const T* fbK, int n, int n2p, int i0, int i1, int i2, T& u0, T& u1, T& u2) {
+    for (int k = 0; k < n2p; k += FB_BATCH) {
+        T ek[FB_BATCH], r0[FB_BATCH], r1[FB_BATCH], r2[FB_BATCH];
+#pragma unroll
+        for (int qq = 0; qq < FB_BATCH; ++qq) {
+            const T* row = fbK + size_t(k + qq) * n;
+            ek[qq] = e[k + qq]; r0[qq] = row[i0]; r1[qq] = row[i1]; r2[qq] = row[i2];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * FB_BATCH, 0);   // the DS reads first ...
+#pragma unroll
+        for (int qq = 0; qq < FB_BATCH; ++qq) { u0 += r0[qq] * ek[qq]; u1 += r1[qq] * ek[qq]; u2 += r2[qq] * ek[qq]; }
+        __builtin_amdgcn_sched_group_barrier(0x002, 3 * FB_BATCH, 0);   // ... then the arithmetic
+    }
+}
+// K e of the stage for this thread's node, through whichever form the gain's size selects (both read e = fbx + g n2p of every beam
+// of the wave, written by the caller before the first barrier here).  Whole wave.
+template <typename T>
+__device__ __forceinline__ void fb_feedback(bool on_matrix_cores, const T (&af)[FBM_MT][FBM_KS], const T* fbx, const T* fbK, T* fbu, int G,
+                                            int g, int n, int n2p, int lane, bool valid, const int (&red)[3], T (&u)[3]) {
+    __syncthreads();
+    u[0] = u[1] = u[2] = T(0);
+    if (on_matrix_cores) {
+        fbm_product<T>(af, fbx, fbu, G, n, n2p, lane);
+        __syncthreads();
+        if (valid) {
+            const T* ub = fbu + size_t(g) * FBM_UPAD;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) u[c] = red[c] >= 0 ? ub[red[c]] : T(0);
+        }
+    } else if (valid) {
+        const int i0 = red[0] >= 0 ? red[0] : 0, i1 = red[1] >= 0 ? red[1] : 0, i2 = red[2] >= 0 ? red[2] : 0;
+        T u0 = T(0), u1 = T(0), u2 = T(0);
+        fb_product_lds<T>(fbx + size_t(g) * n2p, fbK, n, n2p, i0, i1, i2, u0, u1, u2);
+        u[0] = red[0] >= 0 ? u0 : T(0);
+        u[1] = red[1] >= 0 ? u1 : T(0);
+        u[2] = red[2] >= 0 ? u2 : T(0);
+    }
+}
+
 template <typename T, int MODE, int LV, int MAXT, int MINW, bool LEAN, bool FB = false>
 __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p) {
     static_assert(!FB || (MODE == MODE_STEP && !LEAN), "feedback lives in the general stepper");
@@ -596,38 +644,10 @@ __global__ void __launch_bounds__(MAXT, MINW) crb_beam_kernel(const KParams<T> p
                     for (int c = 0; c < 3; ++c)
                         if (red[c] >= 0) { e[red[c]] = rq[c] - xs[c]; e[fb_n + red[c]] = rv[c] - xs[3 + c]; }
                 }
-                __syncthreads();
-                if (fb_mfma) {
-                    fbm_product<T>(fb_af, fbx, fbu, p.G, fb_n, fb_n2p, tp.lane);
-                    __syncthreads();
-                    if (valid) {
-                        const T* ub = fbu + size_t(g) * FBM_UPAD;
+                T ufb[3];
+                fb_feedback<T>(fb_mfma, fb_af, fbx, fbK, fbu, p.G, valid ? g : 0, fb_n, fb_n2p, tp.lane, valid, red, ufb);
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) uadd[c] += red[c] >= 0 ? ub[red[c]] : T(0);
-                    }
-                } else if (valid) {
-                    const int i0 = red[0] >= 0 ? red[0] : 0, i1 = red[1] >= 0 ? red[1] : 0, i2 = red[2] >= 0 ? red[2] : 0;
-                    T u0 = T(0), u1 = T(0), u2 = T(0);
-                    // K e in batches of FB_BATCH columns: all LDS loads of a batch are issued before its first multiply-add
-                    // (one wave per SIMD here, nothing else hides the LDS latency; left to itself the scheduler
-                    // alternates load / wait / multiply-add: 200 cycles per column).  The column count is padded
-                    // to a multiple of the batch with zero columns.
-                    for (int k = 0; k < fb_n2p; k += FB_BATCH) {
-                        T ek[FB_BATCH], r0[FB_BATCH], r1[FB_BATCH], r2[FB_BATCH];
-#pragma unroll
-                        for (int qq = 0; qq < FB_BATCH; ++qq) {
-                            const T* row = fbK + size_t(k + qq) * fb_n;
-                            ek[qq] = e[k + qq]; r0[qq] = row[i0]; r1[qq] = row[i1]; r2[qq] = row[i2];
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x100, 4 * FB_BATCH, 0);   // the DS reads first ...
-#pragma unroll
-                        for (int qq = 0; qq < FB_BATCH; ++qq) { u0 += r0[qq] * ek[qq]; u1 += r1[qq] * ek[qq]; u2 += r2[qq] * ek[qq]; }
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3 * FB_BATCH, 0);   // ... then the arithmetic
-                    }
-                    uadd[0] += red[0] >= 0 ? u0 : T(0);
-                    uadd[1] += red[1] >= 0 ? u1 : T(0);
-                    uadd[2] += red[2] >= 0 ? u2 : T(0);
-                }
+                for (int c = 0; c < 3; ++c) uadd[c] += ufb[c];
             }
             stage_accel<T, LV, false, LEAN>(p, lds, sc, cf, tp, xs, xs + 3, uadd, a);
             const T w = (s == 0 || s == 3) ? T(1) : T(2);

@@ -221,11 +221,15 @@ __host__ __device__ constexpr int lean_minw_f64(int lv, int lognw, bool grav) { 
 // exchanges stay DPP lane shifts; whatever a shift drags across a beam boundary is replaced by 0 with a SELECT (in
 // round A and in every reduction level, lean_reduce_tail<..., ISOLATE>): a diverged wave-mate's Inf / NaN must not
 // reach its neighbours through a 0 * NaN (the reference's beams are independent).
-template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false, bool PACK = false>
+// FB (packed one-wave form): the state feedback u = K (r - x) inside every stage, as in crb_beam_kernel<..., FB> (crb_generic.h: gain
+// in LDS, the product K e on the matrix cores for gains of 21 .. 32 rows) but around THIS kernel's right-hand side -- the
+// general kernel's costs 4000 cycles per stage for a 10-element beam, this one's 1900.  One wave per SIMD (the gain's
+// fragments take 64 more registers).
+template <typename T, int LV, int LOGNW, bool GRAV, int EM, bool HELD = false, bool PACK = false, bool FB = false>
 // fp64: 2 waves/SIMD, 256 VGPRs hold the multipliers.  fp32: the headline shape (<= 4 levels, no gravity, no held
 // input) fits 4 waves/SIMD (128 VGPRs; three 8-byte addresses spill, outside the step loop: config 4 runs 8.1e10
 // element-steps/s at 4 waves against 6.6e10 at 3), the other fp32 instantiations keep 3 waves/SIMD (168 VGPRs)
-__global__ void __launch_bounds__(64 << LOGNW, (sizeof(T) == 4 && LOGNW <= 2) ? ((LV <= 4 && !GRAV && !HELD) ? 4 : 3) : lean_minw_f64(LV, LOGNW, GRAV))
+__global__ void __launch_bounds__(64 << LOGNW, FB ? 1 : ((sizeof(T) == 4 && LOGNW <= 2) ? ((LV <= 4 && !GRAV && !HELD) ? 4 : 3) : lean_minw_f64(LV, LOGNW, GRAV)))
 crb_step_lean_kernel(const KParams<T> p_formal) {
     // The launch parameters are read through the kernarg pointer, which is "laundered" (CRB_FRESH) at the top of
     // every beam and again after the step loop: what the beam prologue / epilogue need (pointers, strides, sizes) is
@@ -245,6 +249,7 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
 #endif
     KParams<T> p = CRB_PARAMS(kp);
     static_assert(!PACK || LOGNW == 0, "packed beams live inside one wave");
+    static_assert(!FB || (PACK && !HELD), "the feedback form is the packed one-wave stepper");
     static_assert(LV >= 1, "lean stepper needs at least one reduction level");
     constexpr int NW = 1 << LOGNW, NT = 64 << LOGNW, RN = LeanRec<T>::N;
     constexpr int NULLT = NT;  // index of the all-zero record / column: "no neighbour"
@@ -320,6 +325,24 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
         }
     };
     if (shared_tables) load_tables(0);
+    // FB: the gain (transposed) and the stage's error vectors of the wave's beams live in LDS (the one-wave form uses none otherwise)
+    const int fb_n = FB ? p.n_red : 0, fb_n2 = 2 * fb_n, fb_n2p = fb_padded(fb_n2), fb_G = FB ? p.G : 0;
+    T* const fbx = reinterpret_cast<T*>(crb_smem);        // [G][2n padded]
+    T* const fbK = fbx + size_t(fb_G) * fb_n2p;           // [2n padded][n]
+    T* const fbu = fbK + size_t(fb_n2p) * fb_n;           // [G][FBM_UPAD]
+    const bool fb_mfma = FB && fb_on_matrix_cores(fb_G, fb_n);
+    T fb_af[FBM_MT][FBM_KS];
+    if (FB) {
+        for (int idx = t; idx < fb_n * fb_n2; idx += NT) {
+            const int i = idx / fb_n2, k = idx - i * fb_n2;
+            fbK[size_t(k) * fb_n + i] = p.fb_gain[idx];
+        }
+        for (int idx = t; idx < (fb_n2p - fb_n2) * fb_n; idx += NT) fbK[size_t(fb_n2) * fb_n + idx] = T(0);
+        for (int idx = t; idx < fb_G * (fb_n2p - fb_n2); idx += NT)
+            fbx[size_t(idx / (fb_n2p - fb_n2)) * fb_n2p + fb_n2 + idx % (fb_n2p - fb_n2)] = T(0);
+        __syncthreads();
+        if (fb_mfma) fbm_gain_fragments<T>(fb_af, fbK, fb_n, fb_n2p, lane);
+    }
     const bool corrected = (p.flags & 4u) != 0;
     const T dt = T(p.dt), hdt = T(0.5 * p.dt), dt6 = T(p.dt / 6.0);
     const size_t plane = size_t(p.n_node) * 4;
@@ -354,6 +377,18 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     if (HELD && valid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) uh[c] = p.u_held[size_t(beam) * plane + node * 4 + c];
+    }
+    int red[3] = {-1, -1, -1};            // FB: reduced indices and reference of this node
+    T rq[3] = {T(0), T(0), T(0)}, rv[3] = {T(0), T(0), T(0)};
+    if (FB && valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            red[c] = p.red_map[3 * node + c];
+            if (red[c] >= 0 && p.fb_ref) {
+                rq[c] = p.fb_ref[size_t(beam) * fb_n2 + red[c]];
+                rv[c] = p.fb_ref[size_t(beam) * fb_n2 + fb_n + red[c]];
+            }
+        }
     }
 
     // ---- left neighbour's q for the very first stage
@@ -407,6 +442,18 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
             for (int c = 0; c < 3; ++c) {
                 pp[c] = ((imp_on && c == p.imp_dof) ? T(1) : T(0)) * amp - fr[c];
                 if (HELD) pp[c] += uh[c];
+            }
+            if (FB) {   // u = K (r - x) of the stage state (lqr_control.py:95-111)
+                T* const e = fbx + size_t(valid ? pg : 0) * fb_n2p;
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (red[c] >= 0) { e[red[c]] = rq[c] - sq[c]; e[fb_n + red[c]] = rv[c] - sv[c]; }
+                }
+                T ufb[3];
+                fb_feedback<T>(fb_mfma, fb_af, fbx, fbK, fbu, fb_G, valid ? pg : 0, fb_n, fb_n2p, lane, valid, red, ufb);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) pp[c] += ufb[c];
             }
             pp[1] += drag_force<T>(dragc, sv[1]);
             if (GRAV) {

@@ -183,6 +183,46 @@ hipError_t launch_lean_grav(const KParams<T>& k, int n_beams, int levels, int lo
 }
 #endif
 
+#if (CRB_LEAN_PART == 0 || CRB_LEAN_PART == 1) && !defined(CRB_FAST_BUILD)
+// the packed one-wave stepper with the state feedback inside its stages (crb_step_lean_kernel<..., FB>): k.G >= 2 beams per wave,
+// gain / reference / reduced map in k; mixed element kinds are evaluated per lane
+namespace {
+template <int LV, bool GRAV>
+hipError_t one_fb(const KParams<T>& k, int n_beams, hipStream_t st) {
+    auto kernel = crb_step_lean_kernel<T, LV, 0, GRAV, EM_MIXED, false, true, true>;
+    const size_t smem = fb_lean_lds_bytes<T>(k.G, k.n_red);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+        if (e != hipSuccess) return e;
+    }
+    const int groups = (n_beams + k.G - 1) / k.G;
+    int grid = groups;
+    const bool shared = k.slot_stride == 0 && k.lv_stride == 0 && k.fin_stride == 0;
+    static int resident = -1;   // (per instantiation)
+    if (shared) {   // a workgroup loads its tables and the gain once and walks over several groups of beams
+        if (resident < 0) resident = resident_groups(kernel, 64, smem);
+        int cap = resident;
+        if (const char* env = std::getenv("CRB_LEAN_MAX_GROUPS")) cap = std::atoi(env);
+        if (cap > 0 && groups > cap) {
+            const int rounds = (groups + cap - 1) / cap;
+            grid = (groups + rounds - 1) / rounds;
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), smem, st, k);
+    return hipGetLastError();
+}
+}  // namespace
+hipError_t launch_lean_feedback(const KParams<T>& k, int n_beams, int levels, bool grav, hipStream_t st) {
+    if (k.G < 2 || !k.fb_gain || !k.red_map) return hipErrorInvalidValue;
+    switch (levels) {
+        case 3: return grav ? one_fb<3, true>(k, n_beams, st) : one_fb<3, false>(k, n_beams, st);
+        case 4: return grav ? one_fb<4, true>(k, n_beams, st) : one_fb<4, false>(k, n_beams, st);
+        case 5: return grav ? one_fb<5, true>(k, n_beams, st) : one_fb<5, false>(k, n_beams, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+#endif
+
 #if CRB_LEAN_PART == 0 || CRB_LEAN_PART == 1
 hipError_t launch_lean(const KParams<T>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st) {
 #ifdef CRB_FAST_BUILD  // kernel-tuning build (make fast): only the config-3 instance

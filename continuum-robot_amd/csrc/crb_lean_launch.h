@@ -10,6 +10,10 @@ namespace crb {
 // levels in 3..6, lognw in 0..3 (callers check eligibility); hipErrorInvalidValue otherwise.
 hipError_t launch_lean(const KParams<double>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
 hipError_t launch_lean(const KParams<float>& k, int n_beams, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);
+// launches the packed one-wave stepper with the LQR feedback inside its stages (crb_step_lean_kernel<..., FB>): k.G >= 2 beams
+// per wave, levels in 3..5, gain / reference / reduced map in k; hipErrorInvalidValue otherwise
+hipError_t launch_lean_feedback(const KParams<double>& k, int n_beams, int levels, bool grav, hipStream_t st);
+hipError_t launch_lean_feedback(const KParams<float>& k, int n_beams, int levels, bool grav, hipStream_t st);
 // launches crb_stage_lean_kernel<T, levels, lognw, grav, elem_mode> on `n_groups` workgroups (each walks
 // over beams blockIdx.x, blockIdx.x + n_groups, ...)
 hipError_t launch_stage_lean(const KParams<double>& k, int n_groups, int levels, int lognw, bool grav, int elem_mode, hipStream_t st);

@@ -1817,6 +1817,14 @@ int fused_feedback_impl(const crb_plan* p, void* x, double t0, double dt, int n_
     k.n_red = p->n_free;
     k.fb_gain = static_cast<const T*>(gain);
     k.fb_ref = static_cast<const T*>(ref);
+    // several beams per wave with 3 .. 5 reduction levels, gravity absent or canonical: the packed LEAN stepper with the feedback
+    // inside its stages (its right-hand side costs half of the general kernel's)
+    const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
+    if (p->G > 1 && lean_eligible(p, nullptr) && p->levels >= 3 && p->levels <= 5 &&
+        fb_lean_lds_bytes<T>(p->G, p->n_free) <= size_t(144) * 1024 && std::getenv("CRB_DISABLE_LEAN_FEEDBACK") == nullptr) {
+        HIP_TRY(crb::launch_lean_feedback(k, p->B, p->levels, grav, st));
+        return CRB_OK;
+    }
     switch (p->levels) {   // (a beam inside one wave: at most 6 levels)
         case 0: return launch_fused_feedback_lv<T, 0>(p, k, st);
         case 1: return launch_fused_feedback_lv<T, 1>(p, k, st);

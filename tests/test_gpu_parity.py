@@ -2164,19 +2164,26 @@ def test_example_scripts_run_and_agree_with_the_oracle():
     assert len(rows) == 3 and np.allclose(rows[2][1], rows[1][1], rtol=1e-3, atol=1e-9), np.abs(rows[2][1] - rows[1][1]).max()   # the tolerance-controlled run (the fixed-step run sees the end of the impulse in one stage of one step)
 
 
+@pytest.mark.parametrize("lean", [True, False])
 @pytest.mark.parametrize("n_e,B,kind,kw,bcs", [
     (6, 5, "linear", dict(enable_gravity=True), None),                                  # the reference's LQR example size
     (6, 70, "nonlinear", dict(fluid_density=1000.0, enable_fluid=True), None),          # several workgroups, 10 beams a wave
     (10, 3, "mixed", dict(fluid_density=1000.0, enable_fluid=True, enable_gravity=True), "pinned"),
+    (10, 40, "linear", dict(enable_gravity=True), None),                                # lqr_control.py's own size: K e on the matrix cores
+    (9, 13, "mixed", dict(fluid_density=1000.0, enable_fluid=True), None),              # 27 rows: matrix cores, partly filled last wave
     (27, 4, "linear", dict(enable_gravity=True), None),                                 # gain of 102 KB: LDS above 64 KB
     (1, 9, "linear", dict(), None),
 ])
-def test_fused_feedback_stepper_matches_the_stage_split_one_and_the_oracle(n_e, B, kind, kw, bcs, monkeypatch):
-    """Closed-loop rollouts of beams that live in one wave take ONE launch (crb_beam_kernel<..., FB>: the gain in LDS,
-    u = K (r - x) formed per stage by the node threads) instead of the stage-split path's eight launches per step:
+def test_fused_feedback_stepper_matches_the_stage_split_one_and_the_oracle(n_e, B, kind, kw, bcs, lean, monkeypatch):
+    """Closed-loop rollouts of beams that live in one wave take ONE launch -- the packed lean stepper with the feedback in its
+    stages (crb_step_lean_kernel<..., FB>: 3 .. 5 reduction levels, gravity absent or canonical) or the general kernel
+    (crb_beam_kernel<..., FB>; CRB_DISABLE_LEAN_FEEDBACK forces it): the gain in LDS, u = K (r - x) formed per stage, on the
+    matrix cores for gains of 21 .. 32 rows -- instead of the stage-split path's eight launches per step:
     against RK4 over the oracle RHS with the feedback in every stage (lqr_control.py:95-111), per DOF block, with
     per-beam references and amplitudes from random states, and against the stage-split path (CRB_FUSED_FEEDBACK=0)."""
     monkeypatch.setenv("CRB_FUSED_FEEDBACK", "1")   # (whenever the gain fits LDS: also where the default would not choose it)
+    if not lean:
+        monkeypatch.setenv("CRB_DISABLE_LEAN_FEEDBACK", "1")
     rng = np.random.default_rng(100 + n_e)
     kinds = ["nonlinear" if i % 3 else "linear" for i in range(n_e)] if kind == "mixed" else kind
     bc = None
