@@ -2219,6 +2219,29 @@ def test_fused_feedback_stepper_matches_the_stage_split_one_and_the_oracle(n_e, 
     assert_blocks(ens2.unpack_state().cpu().numpy(), got, ens.free_index, 1e-10)
 
 
+@pytest.mark.parametrize("lean", [True, False])
+@pytest.mark.parametrize("n_e", [6, 10])
+def test_fused_feedback_stepper_in_single_precision(n_e, lean, monkeypatch):
+    """fp32 plans run the same fused closed-loop kernels (the product K e on v_mfma_f32_16x16x4_f32 for 10 elements, from LDS
+    for 6): the rollout tracks the fp64 one at single precision."""
+    monkeypatch.setenv("CRB_FUSED_FEEDBACK", "1")
+    if not lean:
+        monkeypatch.setenv("CRB_DISABLE_LEAN_FEEDBACK", "1")
+    cols, kw, B = nitinol_columns(n_e, "linear"), dict(enable_gravity=True), 23
+    rng = np.random.default_rng(n_e)
+    outs = []
+    gain = rng.normal(0.0, 2e-2, (3 * n_e, 6 * n_e))
+    x0 = rng.normal(0.0, 1e-4, (B, 6 * n_e))
+    ref = rng.normal(0.0, 1e-4, (B, 6 * n_e))
+    for dtype in (torch.float64, torch.float32):
+        e = ensemble(cols, B, kw, dtype=dtype)
+        assert e.feedback_path() == "fused"
+        e.set_state(x0)
+        e.step_feedback(30, 1e-5, gain, reference=ref, impulse_amp=np.full(B, 0.05))
+        outs.append(e.unpack_state().double().cpu().numpy())
+    assert rel_err(outs[1], outs[0]) < 2e-3
+
+
 @pytest.mark.parametrize("n_e,B,kind,kw,bcs,with_ref,groups", [
     (128, 70, "linear", dict(enable_gravity=True), None, False, None),      # config 5's shape, two row blocks (the second ragged)
     (128, 200, "linear", dict(enable_gravity=True), None, True, 2),          # four row blocks on two groups: groups walk; reference
