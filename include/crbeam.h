@@ -329,9 +329,11 @@ int crb_rk4_stage(const crb_plan* plan, void* x, const void* xs, void* acc, void
  * in *t_end.  CRB_USE_GRAPH=1 in the environment replays one captured step as a hipGraph on a stream of the
  * plan's own (ordered after / before the caller's stream by events).
  * Beams that live in one wave (fewer than 64 thread-carried nodes: the reference's own LQR example has 6 elements)
- * and whose gain fits LDS take ONE launch for the whole rollout instead: the general stepper with the gain resident in
- * LDS and K (r - x) formed per stage by the node threads (12 instead of 36 us per step at 6 elements, 21 instead of
- * 40 - 48 at 16).  CRB_FUSED_FEEDBACK=0 / 1 in the environment forces the stage-split / the fused form.
+ * and whose gain fits LDS take ONE launch for the whole rollout instead: the packed lean stepper (several beams per wave,
+ * 3 .. 5 reduction levels, gravity absent or of the plain cantilever's form; the general stepper otherwise) with the gain
+ * resident in LDS and K (r - x) formed per stage -- on the matrix cores for gains of 21 .. 32 rows, by the node threads
+ * otherwise (10 instead of 36 us per step at 6 and at 10 elements, 21 instead of 40 - 48 at 16 .. 20).
+ * CRB_FUSED_FEEDBACK=0 / 1 in the environment forces the stage-split / the fused form.
  * Large ensembles of beams with 33 .. 128 thread-carried nodes (fp64, one table set) take ONE persistent launch for the
  * whole rollout (csrc/crb_loop.h): groups of workgroups own 64 beams each, keep their slice of the gain in registers,
  * and alternate between the fp64-MFMA product and the stage arithmetic, handing tiles to each other through L2.
