@@ -64,6 +64,39 @@ __host__ __device__ constexpr size_t ctrl_lds_bytes(int NT, bool fb, int n, int 
            64 * sizeof(double);
 }
 
+// The explicit right-hand side a = Minv (u - k(q) + drag + gravity) of ONE beam that lives in one wave, in the lean form (the
+// stage of crb_step_lean_kernel for LOGNW = 0 as a function: the left element's force from a lane shift of q, r = p - f_left of
+// the right neighbour first and ITS neighbours shifted in, the remaining levels by lean_reduce_tail) -- for the closed-loop
+// RK4 of the controlled kernel, whose general right-hand side (stage_accel) costs twice as much at these sizes.
+template <typename T, int LV, bool GRAV>
+__device__ __forceinline__ void lean_wave_rhs(const ElemCoef<T>& ec, bool corrected, T dragc, T hm_own, T gx, T gy, const SolveCoef<T, LV>& cf,
+                                              int t, int lane, int j, int S, bool valid, bool has_right, const T (&sq)[3], const T (&sv)[3],
+                                              const T (&uin)[3], T (&a)[3]) {
+    T qL[3], fl[3], fr[3], pp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) qL[c] = lane_lower<T, 1>(sq[c], lane);    // (lane 0 reads 0: the clamped / absent root)
+    elem_force<T>(ec, qL, sq, corrected, fl, fr);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pp[c] = uin[c] - fr[c];
+    pp[1] += drag_force<T>(dragc, sv[1]);
+    if (GRAV) {
+        const T phiR = lane_higher<T, 1>(sq[2], lane);
+        T g_own[2];
+        gravity_segment<T>(has_right ? T(0.5) * (sq[2] + phiR) : sq[2], gx, gy, hm_own, g_own);
+        pp[0] += g_own[0] + lane_lower<T, 1>(g_own[0], lane);             // (segment j-1 is the left lane's own segment)
+        pp[1] += g_own[1] + lane_lower<T, 1>(g_own[1], lane);
+    }
+    T r[3], rlo[3], rhi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        r[c] = pp[c] - lane_higher<T, 1>(fl[c], lane);
+        rlo[c] = lane_lower<T, 1>(r[c], lane);
+        rhi[c] = lane_higher<T, 1>(r[c], lane);
+    }
+    pcr_apply_level<T>(cf.lv[0], rlo, rhi, r);
+    lean_reduce_tail<T, LV, 0>(cf, nullptr, t, lane, j, S, valid, r, a);
+}
+
 // PACK (lean form, one wave): beams of fewer than 33 slots, G = 64 / S of them per wave (lane = g S + j) as in the packed
 // fixed-step kernels; the beams of a wave share ONE step sequence -- the worst of them decides -- so an ensemble of thousands
 // of short beams fills the chip with a fifth of the waves (control per group of G neighbours instead of per beam).
@@ -71,7 +104,7 @@ template <typename T, int LV, bool FB, int LNW = -1, bool GRAV = false, bool PAC
 __global__ void __launch_bounds__(LNW >= 0 ? (64 << LNW) : 256, 1)
 crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
     static_assert(sizeof(T) == 8, "the controlled steppers are fp64");
-    static_assert(!(FB && LNW >= 0), "the closed loop runs the general RHS");
+    static_assert(!(FB && LNW > 0) && !(FB && PACK), "the closed loop runs one beam per wave: the lean RHS of one wave, or the general one");
     static_assert(LNW < 0 || LV >= 1, "the lean form needs at least one reduction level");
     static_assert(!PACK || LNW == 0, "packed beams live inside one wave");
     constexpr bool SLIM = LNW >= 0;
@@ -180,7 +213,7 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
     T* const fbu = fbK + size_t(fb_n2p) * fb_n;   // [FBM_UPAD]      K e of the stage (matrix-core form, crb_generic.h)
     const bool fb_mfma = FB && fb_on_matrix_cores(1, fb_n);
     T fb_af[FBM_MT][FBM_KS];
-    double* const red = SLIM ? reinterpret_cast<double*>(smem0 + size_t(NTL + 1) * size_t(12 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)))
+    double* const red = (SLIM && !FB) ? reinterpret_cast<double*>(smem0 + size_t(NTL + 1) * size_t(12 + 3 * (LOGNW > 1 ? LOGNW - 1 : 0)))
                              : reinterpret_cast<double*>(FB ? fbu + FBM_UPAD : fbx);   // [NT / 64]; PACK: [64]
     int ridx[3] = {-1, -1, -1};
     T rq[3] = {T(0), T(0), T(0)}, rv[3] = {T(0), T(0), T(0)};
@@ -266,7 +299,13 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) ua[c] += ufb[c];
                         __syncthreads();   // (several waves per beam: every wave has read the error vector before the next stage overwrites it)
-                        stage_accel<T, LV, false, false>(p, lds, sc, cf, tp, xs, xs + 3, ua, a);
+                        if (SLIM) {
+                            const T sq[3] = {xs[0], xs[1], xs[2]}, sv[3] = {xs[3], xs[4], xs[5]};
+                            lean_wave_rhs<T, LV, GRAV>(sc.elem, corrected, dragc, sc.half_mass, gx, gy, cf, tp.t, tp.lane, jl, p.S, valid, has_right,
+                                                       sq, sv, ua, a);
+                        } else {
+                            stage_accel<T, LV, false, false>(p, lds, sc, cf, tp, xs, xs + 3, ua, a);
+                        }
                         const T w = (s == 0 || s == 3) ? T(1) : T(2);
                         const T cs = (s == 2) ? h : hh;
 #pragma unroll

@@ -30,8 +30,17 @@ hipError_t launch_controlled(const KParams<double>& k, const CtrlParams<double>&
 #undef CRB_CTRL_PACK
         return hipErrorInvalidValue;
     }
+    if (lean_lognw >= 0 && feedback) {   // closed-loop RK4 with the lean right-hand side of one wave (the mass matrix's `levels` levels)
+        if (lean_lognw != 0 || threads != 64) return hipErrorInvalidValue;
+#define CRB_CTRL_FBL(LVV) \
+        if (levels == LVV) \
+            return grav ? one_controlled<LVV, true, 0, true>(k, q, threads, lds, st) : one_controlled<LVV, true, 0, false>(k, q, threads, lds, st);
+        CRB_CTRL_FBL(1) CRB_CTRL_FBL(2) CRB_CTRL_FBL(3) CRB_CTRL_FBL(4) CRB_CTRL_FBL(5) CRB_CTRL_FBL(6)
+#undef CRB_CTRL_FBL
+        return hipErrorInvalidValue;
+    }
     if (lean_lognw >= 0) {   // the lean iteration: all ceil(log2 S) levels of a beam of 2 .. 64 / 65 .. 128 / 129 .. 256 slots
-        if (feedback || threads != (64 << lean_lognw)) return hipErrorInvalidValue;
+        if (threads != (64 << lean_lognw)) return hipErrorInvalidValue;
 #define CRB_CTRL_LEAN(LVV, NWW) \
         if (levels == LVV && lean_lognw == NWW) \
             return grav ? one_controlled<LVV, false, NWW, true>(k, q, threads, lds, st) : one_controlled<LVV, false, NWW, false>(k, q, threads, lds, st);

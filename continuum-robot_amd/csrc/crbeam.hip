@@ -1684,16 +1684,17 @@ extern "C" int crb_solve_controlled(const crb_plan* p, void* x, double t0, doubl
     const int threads = p->NT;
     // the lean iteration (crb_stiff.h) where the plan allows it: gravity absent or of the plain cantilever's form
     const bool grav = (p->flags & CRB_FORCE_GRAVITY) != 0;
-    const bool lean = !fb && p->levels_full >= 1 && p->lognw <= 2 && threads == (64 << p->lognw) && (!grav || p->canonical_gravity) &&
-                      std::getenv("CRB_DISABLE_LEAN") == nullptr && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr;
+    const bool lean_shape = p->lognw <= 2 && threads == (64 << p->lognw) && (!grav || p->canonical_gravity) && std::getenv("CRB_DISABLE_LEAN") == nullptr;
+    const bool lean = fb ? (lean_shape && p->lognw == 0 && p->levels >= 1 && p->levels <= 6 && std::getenv("CRB_DISABLE_LEAN_FEEDBACK") == nullptr)
+                         : (lean_shape && p->levels_full >= 1 && std::getenv("CRB_DISABLE_LEAN_IMPLICIT") == nullptr);
     const int lean_lognw = lean ? p->lognw : -1;
     // per_wave: short beams packed G to a wave, one step sequence per wave (the worst of its beams decides)
-    const bool pack = ctl->per_wave != 0 && lean && p->G > 1 && p->lognw == 0 && p->levels_full <= 5;
+    const bool pack = ctl->per_wave != 0 && !fb && lean && p->G > 1 && p->lognw == 0 && p->levels_full <= 5;
     if (ctl->per_wave != 0 && !pack)
         return fail(CRB_EUNSUPPORTED, "crb_solve_controlled: per_wave packs beams of 2 .. 32 thread-carried nodes of the implicit scheme (gravity absent or canonical)");
     if (pack) k.G = p->G;
     HIP_TRY(crb::launch_controlled(k, q, fb ? p->levels : p->levels_full, fb, lean_lognw, grav, pack, threads,
-                                   ctrl_lds_bytes<double>(threads, fb, p->n_free, lean_lognw), st));
+                                   ctrl_lds_bytes<double>(threads, fb, p->n_free, fb ? -1 : lean_lognw), st));
     return CRB_OK;
 }
 

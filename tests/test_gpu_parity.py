@@ -1822,12 +1822,15 @@ def test_controlled_implicit_kernel_takes_the_oracles_steps(n_e, kind, kw, lean,
     assert np.array_equal(ens.unpack_state().cpu().numpy(), y[-1]) and abs(ens.time - n_int * dt_eval) < 1e-15
 
 
+@pytest.mark.parametrize("lean", [True, False])
 @pytest.mark.parametrize("name", ["lqr6", "lqr24"])
-def test_controlled_closed_loop_kernel_takes_the_oracles_steps(golden, name):
+def test_controlled_closed_loop_kernel_takes_the_oracles_steps(golden, name, lean, monkeypatch):
     """crb_solve_controlled, closed-loop RK4 (gain in LDS, u = K (r - x) in every stage): the recorded states are the oracle's
     ``rk4_feedback`` states for the step counts the controller accepted.  With loose tolerances the controller keeps halving
     the rate until the COARSE solution crosses RK4's stability limit (h > ~8.6e-6 s for these loops): its estimate is then
     not finite, the piece is repeated with twice the steps, and the accepted fine solution is a stable one again."""
+    if not lean:        # (the general right-hand side instead of the one-wave lean one)
+        monkeypatch.setenv("CRB_DISABLE_LEAN_FEEDBACK", "1")
     z = golden["g6_lqr_loop"]
     cols, kw = beam_columns(z, name), force_kwargs(z, name)
     K, amp = z[f"{name}/gain"], float(z[f"{name}/amp"])
