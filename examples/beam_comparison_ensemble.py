@@ -27,7 +27,11 @@ def main(argv=None):
     ap.add_argument("--t-final", type=float, default=0.02)
     ap.add_argument("--dt-out", type=float, default=1e-3, help="output interval (DT of the reference's examples)")
     ap.add_argument("--method", default="LSODA")
-    ap.add_argument("--substeps", type=int, default=10)
+    ap.add_argument("--substeps", type=int, default=0,
+                    help="0 (default): the step size follows solve_ivp's tolerances, per rod, inside the kernel -- the reference's "
+                         "call; N > 0: N fixed implicit steps per output interval, no control")
+    ap.add_argument("--rtol", type=float, default=1e-3)
+    ap.add_argument("--atol", type=float, default=1e-6)
     args = ap.parse_args(argv)
 
     none = ForceParams()
@@ -39,13 +43,15 @@ def main(argv=None):
                                        force_params=[fp for _, _, fp in tasks])
     t_eval = np.arange(0.0, args.t_final + 0.5 * args.dt_out, args.dt_out)
     t0 = time.perf_counter()
-    sol = ens.solve_ivp((0.0, float(t_eval[-1])), t_eval, method=args.method, substeps=args.substeps,
-                        impulse_amp=np.full(len(tasks), 0.1))
+    sol = ens.solve_ivp((0.0, float(t_eval[-1])), t_eval, method=args.method, substeps=args.substeps if args.substeps > 0 else "auto",
+                        rtol=args.rtol, atol=args.atol, impulse_amp=np.full(len(tasks), 0.1))
     y = sol.y.cpu().numpy()                      # [B, 2n, n_t]: y[b] is what the reference's sol.y holds for task b
     wall = time.perf_counter() - t0
     tip = ens.reduced_index(args.elements, "w")  # the tip's transverse displacement
     print(f"{len(tasks)} rods x {args.elements} elements, {t_eval.size} output times to t = {t_eval[-1]:.3f} s "
-          f"({sol.method}): {wall * 1e3:.1f} ms")
+          f"({sol.method}{', ' + sol.controller + ' controller' if hasattr(sol, 'controller') else ''}): {wall * 1e3:.1f} ms")
+    if hasattr(sol, "substeps_per_beam"):
+        print("implicit steps taken per rod:", sol.substeps_per_beam.sum(axis=1).tolist())
     print(f"{'elements':<10} {'forces':<8} {'tip w(t_final) [m]':>20} {'max |tip w| [m]':>18}")
     for b, (kind, label, _) in enumerate(tasks):
         w = y[b, tip]

@@ -2154,11 +2154,18 @@ def test_example_scripts_run_and_agree_with_the_oracle():
         from _common import rod
     finally:
         sys.path.remove(ex)
-    y = mods["beam_comparison_ensemble"].main(["--elements", "6", "--t-final", "0.01"])
+    y = mods["beam_comparison_ensemble"].main(["--elements", "6", "--t-final", "0.01", "--substeps", "10"])
     assert y.shape == (9, 36, 11) and np.isfinite(y).all()
     ob = oracle_beam({c: rod(6, "linear")[c].to_numpy() for c in rod(6, "linear").columns})
     want = ob.implicit(np.zeros(36), 1e-4, 100, n_iter=2, amp=0.1)
     assert_blocks(y[0, :, -1], want, ob.red2full(), 1e-9, what="linear dry rod of the example")
+    # the default: the reference's call with its tolerances, the step size chosen per rod inside the kernel.  The uncontrolled
+    # h = 1e-4 s run is what DESIGN says it is next to it: the tip deflection inside the default tolerance band, the rotations
+    # of the unresolved modes a few tens of bands off (measured 26)
+    yc = mods["beam_comparison_ensemble"].main(["--elements", "6", "--t-final", "0.01"])
+    assert yc.shape == y.shape and np.isfinite(yc).all()
+    bands = np.abs(yc[:, :18, -1] - y[:, :18, -1]) / (1e-6 + 1e-3 * np.abs(yc[:, :18, -1]))
+    assert bands[:, 16].max() < 2.0 and bands.max() < 60.0, (bands[:, 16].max(), bands.max())
     rows = mods["lqr_ensemble"].main(["--elements", "4", "--beams", "8", "--t-final", "0.01"])
     (_, open_tip, _), (_, lqr_tip, _) = rows
     assert np.isfinite(open_tip).all() and np.isfinite(lqr_tip).all()
