@@ -615,6 +615,8 @@ def worker(args):
             out["solve_ivp_1s_default_tolerances"] = {
                 "wall_s": walls_ivp[("device", 1)], "wall_s_first_call_with_table_ladder": walls_ivp[("device", 0)],
                 "wall_s_host_loop_controller": walls_ivp[("host", 0)], "launches": 1, "fine_steps_accepted": steps_dev,
+                # (every accepted fine solution of 2m steps comes with a coarse one of m steps: 1.5 steps taken per accepted step, more after a rejection)
+                "us_per_implicit_step_taken": walls_ivp[("device", 1)] / (1.5 * steps_dev) * 1e6,
                 "tip_w_1s": tip, "tip_w_1s_lsoda_tight": -0.41624141,
                 "reference_wall_s": 207.0, "reference_source": "BASELINE.md section 2 (scipy LSODA over the reference RHS, one core)"}
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
