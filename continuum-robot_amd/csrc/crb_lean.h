@@ -348,6 +348,18 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     const size_t plane = size_t(p.n_node) * 4;
     const int n_groups = PACK ? (p.B + p.G - 1) / p.G : p.B;
 
+    // Beam switch without a dependent global load (plans with one table set, one beam per workgroup at a time): while the current
+    // beam steps, the NEXT beam's state records and impulse amplitude are already in flight, and the boundary-condition masks
+    // are three bits of one register instead of three loads per beam -- in-kernel stamps put those loads at 1.5 of the 2.2 us a
+    // beam switch takes (kernarg re-read 0.2, first exchange 0.15, epilogue 0.35).
+    constexpr bool PREFETCH = !PACK && !FB;
+    T nq[3] = {T(0), T(0), T(0)}, nv[3] = {T(0), T(0), T(0)}, namp = T(0);
+    bool have_next = false;
+    int mask_bits = 7;
+    if (PREFETCH && shared_tables && has_slot) {
+        const SlotConst<T>& sc0 = p.slot[j];
+        mask_bits = (sc0.mask[0] != T(0) ? 1 : 0) | (sc0.mask[1] != T(0) ? 2 : 0) | (sc0.mask[2] != T(0) ? 4 : 0);
+    }
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     CRB_FRESH(kp);
     p = CRB_PARAMS(kp);
@@ -364,14 +376,34 @@ crb_step_lean_kernel(const KParams<T> p_formal) {
     const size_t xoff = size_t(valid ? beam : 0) * 2 * plane + node * 4;
     T xq[3] = {T(0), T(0), T(0)}, xv[3] = {T(0), T(0), T(0)};
     T amp = T(0);
-    if (valid) {
-        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];   // (masks are not kept in registers)
+    if (PREFETCH && have_next) {                  // (wave-uniform: a real branch, the loads below are not issued)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const bool on = (mask_bits >> c) & 1;
+            xq[c] = on ? nq[c] : T(0);
+            xv[c] = on ? nv[c] : T(0);
+        }
+        amp = namp;
+    } else if (valid) {
+        const SlotConst<T>& sc = p.slot[size_t(beam) * p.slot_stride + j];   // (per-beam masks are not kept in registers)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             xq[c] = p.x[xoff + c] * sc.mask[c];
             xv[c] = p.x[xoff + plane + c] * sc.mask[c];
         }
         if (p.amp && j == (p.imp_node_b ? p.imp_node_b[beam] - p.off : p.imp_slot)) amp = p.amp[beam];
+    }
+    have_next = false;
+    if (PREFETCH && shared_tables && grp + int(gridDim.x) < n_groups) {   // (wave-uniform)
+        have_next = true;
+        if (has_slot) {
+            const int nb = grp + int(gridDim.x);
+            const size_t noff = size_t(nb) * 2 * plane + size_t(j + p.off) * 4;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { nq[c] = p.x[noff + c]; nv[c] = p.x[noff + plane + c]; }
+            namp = T(0);
+            if (p.amp && j == (p.imp_node_b ? p.imp_node_b[nb] - p.off : p.imp_slot)) namp = p.amp[nb];
+        }
     }
     T uh[3] = {T(0), T(0), T(0)};
     if (HELD && valid) {
