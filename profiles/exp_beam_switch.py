@@ -1,8 +1,6 @@
-"""Experiment (round 3, not taken): launch time of the config-3 stepper for 1 / 20 / 100 fused steps, to test whether the
-fixed cost of a launch is the latency of the per-beam loads at a beam switch.  A build that prefetches the next beam's state and
-impulse amplitude during the current beam's steps and keeps the boundary-condition masks as three bits of one register
-(235 instead of 221 VGPRs) measured the SAME launch times (B = 4096: 62.6 / 615 / 2760 us against 66.3 / 616 / 2757): the
-switch latency is not what a short launch pays for.  usage: [CRB_LIB_PATH=...] python profiles/exp_beam_switch.py"""
+"""Experiment (round 3): launch time of the config-3 stepper for 1 / 20 / 100 fused steps -- what a beam switch costs a short launch.
+A/B against a library built from other sources with CRB_LIB_PATH.  The prefetch of the next beam's state (taken) measured
+62.6 / 626 / 2750 us before and 66.4 / 609 / 2749 us after at B = 4096.  usage: [CRB_LIB_PATH=...] python profiles/exp_beam_switch.py"""
 import os, sys
 ROOT = "/root/repo"
 sys.path[:0] = [ROOT, os.path.join(ROOT, "continuum-robot_amd")]
