@@ -66,7 +66,8 @@ class RecordDesc(C.Structure):
 
 class ControlDesc(C.Structure):
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("first_rate", C.c_double), ("positions_only", C.c_int32),
-                ("n_iter", C.c_int32), ("max_rungs", C.c_int32), ("per_wave", C.c_int32)]
+                ("n_iter", C.c_int32), ("max_rungs", C.c_int32), ("per_wave", C.c_int32), ("series_plane", C.c_int32),
+                ("series_node", C.c_int32), ("series_dof", C.c_int32), ("series_pad", C.c_int32), ("series_out", C.c_void_p)]
 
 
 class NativeError(RuntimeError):

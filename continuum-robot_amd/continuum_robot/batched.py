@@ -646,12 +646,13 @@ class BeamEnsemble:
     def solve_controlled(self, n_intervals: int, dt_eval: float, rtol: float = 1e-3, atol: float = 1e-6, control: str = "all",
                          gain=None, reference=None, impulse_amp=None, impulse_duration: float = 0.01, impulse_index: int = -2,
                          held_force=None, t0: Optional[float] = None, n_iter: int = 2, first_rate: float = 0.0,
-                         max_rungs: int = 0, record: bool = True, per_wave: bool = False):
+                         max_rungs: int = 0, record=True, per_wave: bool = False):
         """``n_intervals`` intervals of length ``dt_eval`` from the resident state with the step size chosen per beam by
         ``rtol`` / ``atol`` INSIDE the kernel, one launch (crb_solve_controlled, csrc/crb_ctrl.h): the implicit midpoint rule,
         or -- with ``gain`` -- RK4 with the feedback in every stage.  Returns (snapshots [n_intervals, B, 2, n_node, 4] or
-        None, stats [B, 4] (fine steps accepted, doublings, status, last rung), steps per beam and interval [B, n_intervals]);
-        raises when a beam could not meet the tolerances."""
+        None -- or, with ``record=(node, param)``, that DOF's series [B, n_intervals] --, stats [B, 4] (fine steps accepted,
+        doublings, status, last rung), steps per beam and interval [B, n_intervals]); raises when a beam could not meet the
+        tolerances."""
         if control not in ("all", "positions"):
             raise ValueError('control must be "all" or "positions"')
         if t0 is not None:
@@ -667,24 +668,32 @@ class BeamEnsemble:
             keep.append(held)
         K = None if gain is None else self._dev(gain, (self.n, 2 * self.n))
         ref = None if reference is None else self._dev(reference, (self.n_beams, 2 * self.n))
-        ctl = nat.ControlDesc(float(rtol), float(atol), float(first_rate), int(control == "positions"), int(n_iter), int(max_rungs),
-                              int(bool(per_wave)))
         n_intervals = int(n_intervals)
-        snaps = torch.zeros((n_intervals,) + tuple(self.state.shape), dtype=self.dtype, device=self.device) if record else None
+        # record: True = whole-state snapshots, False = none, (node, param) = that DOF's series [B, n_intervals] instead (what the
+        # examples read; param "w" / "dw_dt" ...): the first return value is then the series
+        series, sp, sn, sd = None, 0, 0, 0
+        if isinstance(record, tuple):
+            node, param = record
+            vel = param.startswith("d") and param.endswith("_dt")
+            sp, sn, sd = int(vel), int(node), _PARAM[param[1:-3] if vel else param]
+            series = torch.zeros((self.n_beams, max(n_intervals, 1)), dtype=self.dtype, device=self.device)
+        ctl = nat.ControlDesc(float(rtol), float(atol), float(first_rate), int(control == "positions"), int(n_iter), int(max_rungs),
+                              int(bool(per_wave)), sp, sn, sd, 0, series.data_ptr() if series is not None else None)
+        snaps = torch.zeros((n_intervals,) + tuple(self.state.shape), dtype=self.dtype, device=self.device) if record is True else None
         stats = torch.zeros((self.n_beams, 4), dtype=torch.int32, device=self.device)
         used = torch.zeros((self.n_beams, max(n_intervals, 1)), dtype=torch.int32, device=self.device)
         with self._on_device():
             nat.check(self._lib.crb_solve_controlled(self.plan.h, self._ptr(self.state), self.time, float(dt_eval), n_intervals,
                                                      C.byref(ctl), C.byref(desc), self._ptr(K), self._ptr(ref), self._ptr(snaps),
                                                      self._ptr(stats), self._ptr(used), self._stream()))
-        self._keep = keep + [K, ref, snaps, stats, used]
+        self._keep = keep + [K, ref, snaps, stats, used, series]
         st = stats.cpu().numpy()
         if np.any(st[:, 2] != 0):
             bad = int(np.flatnonzero(st[:, 2] != 0)[0])
             raise RuntimeError(f"solve_controlled: the tolerances ask for more steps per interval than the ladder holds "
                                f"(beam {bad}; {int(np.count_nonzero(st[:, 2]))} beams in all)")
         self.time = self.time + n_intervals * float(dt_eval)
-        return snaps, st, used.cpu().numpy()[:, :n_intervals]
+        return (series[:, :n_intervals] if series is not None else snaps), st, used.cpu().numpy()[:, :n_intervals]
 
     def _solve_controlled(self, advance, order, m_first, t0, dt_eval, n_t, first, rtol, atol, control, t_switch=None,
                           max_substeps=1 << 14):

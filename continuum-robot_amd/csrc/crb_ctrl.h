@@ -55,6 +55,8 @@ struct CtrlParams {
     int32_t* stats;             // [B][CTRL_STATS]
     int32_t* used;              // [B][n_intervals] fine steps accepted per t_eval interval, or nullptr
     T* y_out;                   // [n_rec][B][2][n_node][4] or nullptr
+    T* series_out;              // [B][n_intervals] one DOF per t_eval point, or nullptr
+    int series_slot, series_comp;   // its slot (node - off) and component (3 plane + dof)
 };
 
 template <typename T>
@@ -411,6 +413,12 @@ crb_controlled_kernel(const KParams<T> p, const CtrlParams<T> q) {
             q.used[size_t(beam) * q.n_intervals + P.interval] = in_interval;
         }
         if (pc + 1 == q.n_pieces || q.pieces[pc + 1].interval != P.interval) in_interval = 0;
+        if (q.series_out && valid && jl == q.series_slot && (pc + 1 == q.n_pieces || q.pieces[pc + 1].interval != P.interval)) {
+            T val = ys[0];
+#pragma unroll
+            for (int c = 1; c < 6; ++c) val = (c == q.series_comp) ? ys[c] : val;
+            q.series_out[size_t(beam) * q.n_intervals + P.interval] = val;
+        }
         if (q.y_out && valid && P.rec >= 0) {
             T* snap = q.y_out + size_t(P.rec) * size_t(p.B) * 2 * plane + xoff;
 #pragma unroll

@@ -1664,6 +1664,17 @@ extern "C" int crb_solve_controlled(const crb_plan* p, void* x, double t0, doubl
     q.stats = static_cast<int32_t*>(stats);
     q.used = static_cast<int32_t*>(used);
     q.y_out = static_cast<double*>(y_out);
+    q.series_out = nullptr; q.series_slot = -1; q.series_comp = 0;
+    if (ctl->series_out) {
+        if (ctl->series_plane < 0 || ctl->series_plane > 1 || ctl->series_node < 0 || ctl->series_node >= p->n_node || ctl->series_dof < 0 ||
+            ctl->series_dof > 2)
+            return fail(CRB_EINVAL, "crb_solve_controlled: bad series description");
+        if (ctl->series_node - p->off >= 0) {   // (a node without a thread slot -- the fixed root -- stays at the caller's zeros)
+            q.series_out = static_cast<double*>(ctl->series_out);
+            q.series_slot = ctl->series_node - p->off;
+            q.series_comp = 3 * ctl->series_plane + ctl->series_dof;
+        }
+    }
 
     KParams<double> k = base_params<double>(p);
     k.G = 1;

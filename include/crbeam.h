@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRB_VERSION 105
+#define CRB_VERSION 106
 
 enum { CRB_OK = 0, CRB_EINVAL = -1, CRB_EHIP = -2, CRB_ENODEV = -3, CRB_EUNSUPPORTED = -4 };
 enum { CRB_F64 = 0, CRB_F32 = 1 };
@@ -273,6 +273,11 @@ typedef struct crb_control_desc {
     int32_t per_wave;        /* 0: every beam its own step sequence (one workgroup per beam).  1 (implicit scheme, beams of 2 .. 32
                               * thread-carried nodes): G = 64 / n_slots beams share a wave AND its step sequence -- the worst of them
                               * decides -- so thousands of short beams fill the chip with a fifth of the waves */
+    /* one DOF on the t_eval grid instead of (or next to) whole-state snapshots -- what the examples read (tip displacement,
+     * lqr_control.py:168): series_out != NULL: device [B][n_intervals], plan dtype, series_out[b][k] = x[b][plane][node][dof] at
+     * t0 + (k + 1) dt_eval (4096 beams x 1000 outputs: 33 MB instead of the 2.9 GB of y_out) */
+    int32_t series_plane, series_node, series_dof, series_pad;
+    void* series_out;
 } crb_control_desc;
 int crb_solve_controlled(const crb_plan* plan, void* x, double t0, double dt_eval, int n_intervals,
                          const crb_control_desc* control, const crb_input_desc* input, const void* gain, const void* ref,

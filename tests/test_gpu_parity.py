@@ -36,7 +36,7 @@ def ensemble(cols, n_beams, kw=None, dtype=None, node_bc=None, corrected_axial=F
 def test_native_library_is_the_loaded_path():
     from continuum_robot import _native as nat
 
-    assert nat.load().crb_version() == 105
+    assert nat.load().crb_version() == 106
     assert torch.cuda.is_available()
 
 
@@ -1901,6 +1901,30 @@ def test_packed_controlled_kernel_shares_a_step_sequence_per_wave(n_e, kw):
     big = ensemble(nitinol_columns(70, "linear"), 2, kw)
     with pytest.raises(ValueError, match="device-packed"):
         big.solve_ivp((0.0, 0.0035), np.arange(0.0, 0.0035, 0.001), method="LSODA", controller="device-packed")
+
+
+def test_controlled_solver_records_one_dof_instead_of_snapshots(golden):
+    """crb_solve_controlled's series output (``record=(node, param)``): the tip displacement on the t_eval grid -- what the examples
+    read from sol.y (lqr_control.py:168, example_utilities.py:173-205) -- without the whole-state snapshots: equal, bit for bit,
+    to that DOF of the snapshots of the same run; the open loop and the closed loop, displacement and velocity."""
+    z = golden["g6_lqr_loop"]
+    cols, kw = beam_columns(z, "lqr6"), force_kwargs(z, "lqr6")
+    K = z["lqr6/gain"]
+    B, n_int = 5, 6
+    amps = 0.1 * (1.0 + np.arange(B))
+    for gain, tol in ((None, dict(rtol=1e-3, atol=1e-6)), (K, dict(rtol=1e-6, atol=1e-9))):
+        for param in ("w", "dw_dt"):
+            a, b = ensemble(cols, B, kw), ensemble(cols, B, kw)
+            snaps, st_a, used_a = a.solve_controlled(n_int, 1e-3, gain=gain, impulse_amp=amps, impulse_duration=2.5e-3, t0=0.0, **tol)
+            series, st_b, used_b = b.solve_controlled(n_int, 1e-3, gain=gain, impulse_amp=amps, impulse_duration=2.5e-3, t0=0.0,
+                                                      record=(a.n_elem, param), **tol)
+            assert tuple(series.shape) == (B, n_int) and np.array_equal(used_a, used_b)
+            y = a.unpack_snapshots(snaps).cpu().numpy()          # [n_int, B, 2n]
+            idx = a.reduced_index(a.n_elem, "w") + (a.n if param == "dw_dt" else 0)
+            assert np.array_equal(series.cpu().numpy(), y[:, :, idx].T), (gain is not None, param)
+            assert np.array_equal(a.state.cpu().numpy(), b.state.cpu().numpy())
+    with pytest.raises(Exception, match="series"):
+        ensemble(cols, 2, kw).solve_controlled(2, 1e-3, record=(99, "w"))
 
 
 def test_controlled_steppers_give_every_beam_its_own_step_sequence(golden):

@@ -31,7 +31,7 @@ def host_plan(cols, node_bc=None, dtype="f64", **kw):
 def test_library_loads_and_exports_every_declared_symbol():
     nat = native()
     lib = nat.load()
-    assert lib.crb_version() == 105
+    assert lib.crb_version() == 106
     hdr = open(os.path.join(ROOT, "include", "crbeam.h")).read()
     names = set(re.findall(r"\b(crb_[a-z0-9_]+)\s*\(", hdr))
     assert {"crb_plan_create", "crb_step_rk4", "crb_rhs", "crb_internal_force", "crb_pack_state"} <= names
