@@ -645,11 +645,12 @@ class BeamEnsemble:
 
     def solve_controlled(self, n_intervals: int, dt_eval: float, rtol: float = 1e-3, atol: float = 1e-6, control: str = "all",
                          gain=None, reference=None, impulse_amp=None, impulse_duration: float = 0.01, impulse_index: int = -2,
-                         held_force=None, t0: Optional[float] = None, n_iter: int = 2, first_rate: float = 0.0,
+                         held_force=None, t0: Optional[float] = None, n_iter: int = 1, first_rate: float = 0.0,
                          max_rungs: int = 0, record=True, per_wave: bool = False):
         """``n_intervals`` intervals of length ``dt_eval`` from the resident state with the step size chosen per beam by
         ``rtol`` / ``atol`` INSIDE the kernel, one launch (crb_solve_controlled, csrc/crb_ctrl.h): the implicit midpoint rule,
-        or -- with ``gain`` -- RK4 with the feedback in every stage.  Returns (snapshots [n_intervals, B, 2, n_node, 4] or
+        or -- with ``gain`` -- RK4 with the feedback in every stage.  ``n_iter``: modified-Newton iterations per implicit step (1: at
+        the controller's step sizes the previous step's iterate is converged after one, profiles/exp_niter.py).  Returns (snapshots [n_intervals, B, 2, n_node, 4] or
         None -- or, with ``record=(node, param)``, that DOF's series [B, n_intervals] --, stats [B, 4] (fine steps accepted,
         doublings, status, last rung), steps per beam and interval [B, n_intervals]); raises when a beam could not meet the
         tolerances."""

@@ -268,7 +268,7 @@ typedef struct crb_control_desc {
     double rtol, atol;
     double first_rate;       /* steps per second of the first coarse solution; <= 0: 1e4 (implicit) / 2e5 (closed-loop RK4) */
     int32_t positions_only;  /* measure the position half of the state only */
-    int32_t n_iter;          /* implicit scheme: modified-Newton iterations per step; <= 0: 2 */
+    int32_t n_iter;          /* implicit scheme: modified-Newton iterations per step; <= 0: 1 (enough at the controller's step sizes) */
     int32_t max_rungs;       /* <= 0: 15 */
     int32_t per_wave;        /* 0: every beam its own step sequence (one workgroup per beam).  1 (implicit scheme, beams of 2 .. 32
                               * thread-carried nodes): G = 64 / n_slots beams share a wave AND its step sequence -- the worst of them

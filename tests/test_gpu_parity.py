@@ -1767,7 +1767,7 @@ def test_solve_ivp_closed_loop_follows_the_tolerances(golden, name, T, controlle
         e2.solve_ivp((0.0, 0.003), t_eval[:4], method="RK45", gain=K)
 
 
-def _replay_controlled(ob, x0, t0, dt_eval, used, amp, t_switch, gain=None, n_iter=2):
+def _replay_controlled(ob, x0, t0, dt_eval, used, amp, t_switch, gain=None, n_iter=1):
     """The oracle's fixed-step schemes driven with the step counts the in-kernel controller ACCEPTED: per t_eval interval
     ``used[k]`` steps of dt_eval / used[k] (the implicit scheme restarts its iterate at every interval, as the kernel does)."""
     x, out = np.array(x0, dtype=np.float64), []
@@ -1888,7 +1888,7 @@ def test_packed_controlled_kernel_shares_a_step_sequence_per_wave(n_e, kw):
         for k in range(n_int):
             start = x0[b] if k == 0 else y[k - 1, b]
             m = int(used[b, k])
-            want = ob.implicit(start, dt_eval / m, m, n_iter=2, amp=amps[b], duration=2e-3, t0=k * dt_eval)
+            want = ob.implicit(start, dt_eval / m, m, n_iter=1, amp=amps[b], duration=2e-3, t0=k * dt_eval)
             assert_blocks(y[k, b], want, ens.free_index, 2e-9, what=(b, k, m))
     alone = ensemble(cols, B, kw)
     alone.set_state(x0)
@@ -2098,7 +2098,7 @@ def test_controlled_implicit_kernel_on_heterogeneous_ensembles(seed):
                 start = ens.beam_state(b, y[k])
                 continue
             m = int(used[b, k])
-            want = obs[b].implicit(start, dt_eval / m, m, n_iter=2, amp=amps[b], duration=1.5e-3, t0=k * dt_eval)
+            want = obs[b].implicit(start, dt_eval / m, m, n_iter=1, amp=amps[b], duration=1.5e-3, t0=k * dt_eval)
             assert_blocks(ens.beam_state(b, y[k]), want, obs[b].red2full(), 5e-9, what=(seed, b, k, m, int(sizes[b])))
             start = ens.beam_state(b, y[k])
 
@@ -2156,7 +2156,7 @@ def test_randomised_controlled_runs_replay_on_the_oracle(seed):
                 continue                                  # (the cut interval: two pieces with their own step counts)
             start = x0[b] if k == 0 else y[k - 1, b]
             m = int(used[b, k])
-            want = ob.implicit(start, dt_eval / m, m, n_iter=2, amp=0.0 if mode == 2 else amps[b], duration=t_sw if t_sw else 0.0,
+            want = ob.implicit(start, dt_eval / m, m, n_iter=1, amp=0.0 if mode == 2 else amps[b], duration=t_sw if t_sw else 0.0,
                                t0=k * dt_eval, u_held=None if held is None else held[b])
             assert_blocks(y[k, b], want, ens.free_index, 5e-9, what=(seed, n_e, kind, b, k, m, per_wave, control))
 
