@@ -2253,6 +2253,31 @@ def test_fused_feedback_stepper_matches_the_stage_split_one_and_the_oracle(n_e, 
     assert_blocks(ens2.unpack_state().cpu().numpy(), got, ens.free_index, 1e-10)
 
 
+@pytest.mark.parametrize("n_e", [6, 10])
+def test_fused_feedback_stepper_walks_over_groups_of_beams(n_e, monkeypatch):
+    """The packed lean stepper with the feedback loads the gain (and its matrix-core fragments) once per workgroup and WALKS over
+    several groups of beams when the ensemble is larger than what is resident (CRB_LEAN_MAX_GROUPS = 2 here: two workgroups for
+    70 beams): reduced indices, references and amplitudes are per group, the error vectors of a finished group must not leak
+    into the next one; the last group is partly filled."""
+    monkeypatch.setenv("CRB_FUSED_FEEDBACK", "1")
+    monkeypatch.setenv("CRB_LEAN_MAX_GROUPS", "2")
+    cols, kw, B = nitinol_columns(n_e, "linear"), dict(enable_gravity=True), 70
+    rng = np.random.default_rng(50 + n_e)
+    ens = ensemble(cols, B, kw)
+    n = ens.n
+    gain = rng.normal(0.0, 2e-2, (n, 2 * n))
+    ref = rng.normal(0.0, 1e-4, (B, 2 * n))
+    x0 = rng.normal(0.0, 1e-4, (B, 2 * n))
+    amps = 0.02 * (1.0 + np.arange(B))
+    ens.set_state(x0)
+    ens.step_feedback(40, 1e-5, gain, reference=ref, impulse_amp=amps)
+    got = ens.unpack_state().cpu().numpy()
+    ob = oracle_beam(cols, **kw)
+    for b in (0, 1, 8, 9, 17, 35, 62, 63, 68, 69):
+        want = ob.rk4_feedback(x0[b], 1e-5, 40, gain, reference=ref[b], amp=amps[b])
+        assert_blocks(got[b], want, ens.free_index, 1e-9, what=b)
+
+
 @pytest.mark.parametrize("lean", [True, False])
 @pytest.mark.parametrize("n_e", [6, 10])
 def test_fused_feedback_stepper_in_single_precision(n_e, lean, monkeypatch):
